@@ -1,0 +1,134 @@
+"""Host-side preparation of the per-(sample, view) camera records the HIP kernels consume.
+
+The reference does this work inside its batch x view Python loop, with ~6 device->host
+syncs and one OpenCV call per (sample, view)
+(/root/reference/lib/models/project_layer.py:64-75, lib/utils/transforms.py:61-103,
+lib/utils/cameras.py:13-24).  Here the whole batch is packed in one vectorised numpy pass
+into a (B, V, 32) fp32 table (layout: include/sp3d.h `SP3D_CAM_*`) and uploaded with ONE
+host->device copy; the table is cached while the caller keeps passing the same ``meta``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+CAM_STRIDE = 32
+# field offsets inside a record (keep in sync with include/sp3d.h)
+CAM_R, CAM_T, CAM_F, CAM_C, CAM_K, CAM_P, CAM_A, CAM_W0, CAM_H0, CAM_FLIP = 0, 9, 12, 14, 16, 19, 21, 27, 28, 29
+
+
+def _np(x, dtype=None):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    x = np.asarray(x)
+    return x if dtype is None else x.astype(dtype)
+
+
+def get_affine_transform_batch(center, scale, rot, output_size) -> np.ndarray:
+    """Batched twin of ``get_affine_transform(center, scale, rot, output_size)`` (inv=0, shift=0).
+
+    Follows /root/reference/lib/utils/transforms.py:61-103 step by step, including the
+    float32 storage of the three src/dst points (:86-96) before the float64 3-point solve
+    that ``cv2.getAffineTransform`` performs (:99-101).
+      center (n,2) float64 | scale (n,2) float32 | rot (n,) degrees -> (n,2,3) float64
+    """
+    center = np.asarray(center, np.float64).reshape(-1, 2)
+    n = center.shape[0]
+    scale = np.asarray(scale, np.float32).reshape(n, 2)
+    rot = np.asarray(rot, np.float64).reshape(n)
+    scale_tmp = scale * np.float32(200.0)                                    # :75 (float32)
+    src_w = scale_tmp[:, 0].astype(np.float64)
+    src_h = scale_tmp[:, 1].astype(np.float64)
+    dst_w, dst_h = float(output_size[0]), float(output_size[1])
+    rot_rad = np.pi * rot / 180.0                                            # :79
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    wide = src_w >= src_h                                                    # :80
+    spx = np.where(wide, 0.0, src_h * -0.5)
+    spy = np.where(wide, src_w * -0.5, 0.0)
+    src_dir = np.stack([spx * cs - spy * sn, spx * sn + spy * cs], 1)        # get_dir :131-138
+    dst_dir = np.where(wide[:, None], np.array([0.0, dst_w * -0.5]), np.array([dst_h * -0.5, 0.0])).astype(np.float32)
+
+    src = np.zeros((n, 3, 2), np.float32)
+    dst = np.zeros((n, 3, 2), np.float32)
+    src[:, 0] = center                                                       # :89
+    src[:, 1] = center + src_dir                                             # :90
+    dst[:, 0] = [dst_w * 0.5, dst_h * 0.5]                                   # :91
+    dst[:, 1] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir               # :92
+
+    def third(a, b):                                                         # get_3rd_point :126-128 (float32)
+        d = a - b
+        return b + np.stack([-d[:, 1], d[:, 0]], 1).astype(np.float32)
+
+    src[:, 2] = third(src[:, 0], src[:, 1])
+    dst[:, 2] = third(dst[:, 0], dst[:, 1])
+
+    s = src.astype(np.float64)
+    d = dst.astype(np.float64)
+    A = np.zeros((n, 6, 6))
+    rhs = np.zeros((n, 6))
+    for i in range(3):
+        A[:, 2 * i, 0], A[:, 2 * i, 1], A[:, 2 * i, 2] = s[:, i, 0], s[:, i, 1], 1.0
+        A[:, 2 * i + 1, 3], A[:, 2 * i + 1, 4], A[:, 2 * i + 1, 5] = s[:, i, 0], s[:, i, 1], 1.0
+        rhs[:, 2 * i] = d[:, i, 0]
+        rhs[:, 2 * i + 1] = d[:, i, 1]
+    return np.linalg.solve(A, rhs[:, :, None])[:, :, 0].reshape(n, 2, 3)
+
+
+def pack_cameras(meta: Sequence[dict], batch: int, img_size: Sequence[int],
+                 flip_xcoords: Optional[torch.Tensor] = None) -> np.ndarray:
+    """meta: list[V] of collated dicts (App. B of SURVEY.md) -> (B, V, 32) float32 table.
+
+    Field semantics per reference line:
+      R,T,f,c,k,p  fp32 casts of the camera dict          (cameras.py:13-24)
+      A            fp32 cast of get_affine_transform(...) (project_layer.py:69-72)
+      W0,H0        ``center * 2`` compared in fp32         (project_layer.py:68,78-79)
+      flip         ``flip_xcoords[i]``                     (project_layer.py:82)
+    """
+    V = len(meta)
+    B = int(batch)
+    tab = np.zeros((B, V, CAM_STRIDE), np.float32)
+    flips = None if flip_xcoords is None else _np(flip_xcoords).astype(bool).reshape(B)
+    for c in range(V):
+        m = meta[c]
+        cam = m["camera"]
+        center = _np(m["center"], np.float64).reshape(B, 2)
+        scale = _np(m["scale"]).reshape(B, -1)
+        if scale.shape[1] == 1:                                              # scalar scale -> [s, s] (transforms.py:72-73)
+            scale = np.repeat(scale, 2, 1)
+        rot = _np(m["rotation"], np.float64).reshape(B)
+        A = get_affine_transform_batch(center, scale.astype(np.float32), rot, img_size)
+        tab[:, c, CAM_R:CAM_R + 9] = _np(cam["R"], np.float32).reshape(B, 9)
+        tab[:, c, CAM_T:CAM_T + 3] = _np(cam["T"], np.float32).reshape(B, 3)
+        tab[:, c, CAM_F] = _np(cam["fx"], np.float32).reshape(B)
+        tab[:, c, CAM_F + 1] = _np(cam["fy"], np.float32).reshape(B)
+        tab[:, c, CAM_C] = _np(cam["cx"], np.float32).reshape(B)
+        tab[:, c, CAM_C + 1] = _np(cam["cy"], np.float32).reshape(B)
+        tab[:, c, CAM_K:CAM_K + 3] = _np(cam["k"], np.float32).reshape(B, 3)
+        tab[:, c, CAM_P:CAM_P + 2] = _np(cam["p"], np.float32).reshape(B, 2)
+        tab[:, c, CAM_A:CAM_A + 6] = A.astype(np.float32).reshape(B, 6)
+        tab[:, c, CAM_W0] = (center[:, 0] * 2.0).astype(np.float32)
+        tab[:, c, CAM_H0] = (center[:, 1] * 2.0).astype(np.float32)
+        if flips is not None:
+            tab[:, c, CAM_FLIP] = flips.astype(np.float32)
+    return tab
+
+
+def _tensor_key(t):
+    if isinstance(t, torch.Tensor):
+        return (id(t), t._version, t.data_ptr())
+    return (id(t),)
+
+
+def meta_cache_key(meta: Sequence[dict], flip_xcoords, img_size) -> tuple:
+    """Identity+version key of every tensor ``pack_cameras`` reads (cheap; no data access)."""
+    key: List = [tuple(int(v) for v in img_size)]
+    for m in meta:
+        key.append(_tensor_key(m["center"]))
+        key.append(_tensor_key(m["scale"]))
+        key.append(_tensor_key(m["rotation"]))
+        for k in ("R", "T", "fx", "fy", "cx", "cy", "k", "p"):
+            key.append(_tensor_key(m["camera"][k]))
+    key.append(None if flip_xcoords is None else _tensor_key(flip_xcoords))
+    return tuple(key)

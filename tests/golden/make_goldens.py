@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE'S OWN PYTHON on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box never has it):
+
+    python tests/golden/make_goldens.py
+
+The reference is imported unmodified from /root/reference/lib with three import shims
+(SURVEY.md App. C): a ``cv2`` stand-in exposing ``getAffineTransform`` (the same 3-point
+linear system OpenCV solves, in float64 - the only cv2 symbol the path touches,
+lib/utils/transforms.py:99-101), an empty ``vedo`` stub and a bare ``models`` package
+(bypasses lib/models/__init__.py, which drags in GUI stacks).  Nothing from the reference
+is copied: only INPUT descriptions (seeds / small tensors) and the reference's OUTPUTS are
+stored, as .npz files next to this script.
+
+Parity pin status: the reference ships no tests or golden vectors of its own (SURVEY.md
+§4), so these files - outputs of the reference run here with torch 2.10 CPU - are the pin.
+cv2 itself is absent from this image; its arithmetic is restated by the shim (exact for
+rot=0, <=1e-12 otherwise).
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/lib"
+
+warnings.filterwarnings("ignore")
+
+
+def _install_shims():
+    sys.path.insert(0, REF)
+    cv2 = types.ModuleType("cv2")
+
+    def getAffineTransform(src, dst):
+        src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+        A = np.zeros((6, 6))
+        b = np.zeros(6)
+        for i in range(3):
+            A[2 * i] = [src[i, 0], src[i, 1], 1, 0, 0, 0]
+            b[2 * i] = dst[i, 0]
+            A[2 * i + 1] = [0, 0, 0, src[i, 0], src[i, 1], 1]
+            b[2 * i + 1] = dst[i, 1]
+        return np.linalg.solve(A, b).reshape(2, 3)
+
+    cv2.getAffineTransform = getAffineTransform
+    cv2.imshow = lambda *a, **k: None
+    sys.modules["cv2"] = cv2
+    vedo = types.ModuleType("vedo")
+    vedo.Volume = object
+    vedo.show = lambda *a, **k: None
+    sys.modules["vedo"] = vedo
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [REF + "/models"]
+    sys.modules["models"] = pkg
+
+
+class AD(dict):
+    """attribute dict standing in for easydict in cfg stubs"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def make_cfg(image_size, heatmap_size, space_size, space_center, cube, fine_grid, fine_cube,
+             num_joints, roothm=False, threshold=0.3, max_people=10):
+    return AD(
+        NETWORK=AD(IMAGE_SIZE=list(image_size), HEATMAP_SIZE=list(heatmap_size),
+                   NUM_JOINTS=num_joints, ROOTNET_ROOTHM=roothm, BETA=100.0),
+        MULTI_PERSON=AD(SPACE_SIZE=list(space_size), SPACE_CENTER=list(space_center),
+                        INITIAL_CUBE_SIZE=list(cube), MAX_PEOPLE_NUM=max_people, THRESHOLD=threshold),
+        PICT_STRUCT=AD(GRID_SIZE=list(fine_grid), CUBE_SIZE=list(fine_cube)),
+        DATASET=AD(ROOTIDX=2, ROOTIDX_PSEUDO=2),
+    )
+
+
+def main():
+    _install_shims()
+    from models.project_layer import ProjectLayer
+    from models.v2v_net import V2VNet
+    from models.cuboid_proposal_net import CuboidProposalNet
+    from models.pose_regression_net import PoseRegressionNet
+    from core.proposal import nms
+    import utils.cameras as rcams
+    from utils.transforms import get_affine_transform
+
+    from selfpose3d_amd import synthetic as syn
+
+    torch.set_num_threads(8)
+    out = {}
+
+    # ------------------------------------------------------------------ affine (a8)
+    cases = []
+    for center in ([960.0, 540.0], [516.0, 388.0], [180.0, 144.0]):
+        for img in ([960, 512], [384, 288], [96, 72]):
+            base = syn.get_scale((center[0] * 2, center[1] * 2), img)
+            for rot in (0, 0.0, 30.0, -30.0, 12.5, 90.0):
+                for mult in (1.0, 1.3, 0.8):
+                    sc = (base * np.float32(mult)).astype(np.float32)
+                    tr = get_affine_transform(np.array(center), sc, rot, img)
+                    cases.append((center, sc, float(rot), img, np.asarray(tr, np.float64)))
+    np.savez(os.path.join(HERE, "affine.npz"),
+             center=np.array([c[0] for c in cases], np.float64),
+             scale=np.array([c[1] for c in cases], np.float32),
+             rot=np.array([c[2] for c in cases], np.float64),
+             img=np.array([c[3] for c in cases], np.int64),
+             trans=np.array([c[4] for c in cases], np.float64))
+    print("affine:", len(cases))
+
+    # ------------------------------------------------------------------ camera projection (a4,a5)
+    rng = np.random.default_rng(11)
+    pts = np.concatenate([
+        rng.uniform([-4000, -4500, -200], [4000, 3500, 1800], size=(400, 3)),
+        np.array([[0, -500, 800], [3000, -500, 2000], [2999.9, -500.0, 2000.0], [0, 0, 0]], np.float64),
+    ]).astype(np.float32)
+    cams = syn.ring_cameras(5)
+    proj = []
+    for cam in cams:
+        proj.append(rcams.project_pose(torch.from_numpy(pts), cam).numpy())
+    np.savez(os.path.join(HERE, "project_pose.npz"), pts=pts, px=np.stack(proj))
+    print("project_pose:", np.stack(proj).shape)
+
+    # ------------------------------------------------------------------ unprojection (a2,a3,a6-a12)
+    def run_project(name, B, V, J, img, hm, grid_size, grid_center, cube, hm_kind="random", seed=0,
+                    rotations=None, scale_mults=None, flip=None, ssv_style=False, store="full",
+                    stride=37, with_grad=False):
+        cfg = make_cfg(img, hm, syn.SPACE_SIZE, syn.SPACE_CENTER, cube, grid_size, cube, J)
+        layer = ProjectLayer(cfg)
+        meta = syn.make_meta(B, V, img, rotations=rotations, scale_mults=scale_mults, ssv_style=ssv_style)
+        if hm_kind == "random":
+            hms = syn.random_heatmaps(B, V, J, hm[1], hm[0], seed=seed)
+        else:
+            hms, _ = syn.people_heatmaps(B, V, J, hm[1], hm[0], img, seed=seed)
+        if with_grad:
+            hms = [h.clone().requires_grad_(True) for h in hms]
+        gc = grid_center
+        if isinstance(gc, np.ndarray):
+            gc_t = torch.from_numpy(gc)
+        else:
+            gc_t = gc
+        flip_t = None if flip is None else torch.tensor(flip, dtype=torch.bool)
+        cubes, grids = layer(hms, meta, list(grid_size), gc_t, list(cube), flip_xcoords=flip_t)
+        rec = dict(B=B, V=V, J=J, img=np.array(img), hm=np.array(hm), grid_size=np.array(grid_size, np.float64),
+                   cube=np.array(cube), hm_kind=hm_kind, seed=seed,
+                   grid_center=np.asarray(gc, np.float64) if not isinstance(gc, list) else np.array(gc, np.float64),
+                   center_is_list=isinstance(gc, list),
+                   rotations=np.array([] if rotations is None else rotations, np.float64),
+                   scale_mults=np.array([] if scale_mults is None else scale_mults, np.float64),
+                   flip=np.array([] if flip is None else flip, bool), ssv_style=ssv_style,
+                   hm_sum=np.array([float(h.detach().double().sum()) for h in hms]))
+        c = cubes.detach().numpy()
+        g = grids.detach().numpy()
+        rec["cubes_sum"] = np.float64(c.astype(np.float64).sum())
+        rec["cubes_sum_per_joint"] = c.astype(np.float64).sum(axis=(0, 2, 3, 4))
+        rec["grids_sum"] = g.astype(np.float64).sum(axis=(0, 1))
+        if store == "full":
+            rec["cubes"] = c
+            rec["grids"] = g
+        else:
+            N = c.shape[2] * c.shape[3] * c.shape[4]
+            idx = np.arange(0, N, stride)
+            rec["sub_idx"] = idx
+            rec["cubes_sub"] = c.reshape(B, J, N)[:, :, idx]
+            rec["grids_sub"] = g[:, idx]
+        if with_grad:
+            wrng = np.random.default_rng(seed + 101)
+            wgt = torch.from_numpy(wrng.standard_normal(c.shape).astype(np.float32))
+            (cubes * wgt).sum().backward()
+            rec["grad_hm"] = np.stack([h.grad.numpy() for h in hms])
+            rec["grad_seed"] = seed + 101
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+        print(name, "cubes", c.shape, "sum", rec["cubes_sum"], "nonzero frac", float((c != 0).mean()))
+        return cubes.detach(), grids.detach(), hms, meta
+
+    center_list = [list(syn.SPACE_CENTER)]
+    # small coarse, plain validation path (rotation 0 int64, float64 cameras)
+    run_project("unproj_coarse_small", 2, 3, 4, (96, 72), (24, 18), syn.SPACE_SIZE, center_list, (8, 8, 4))
+    # ragged / odd sizes: J=1 (root heat-map only), V=1, non-multiple-of-anything cube
+    run_project("unproj_coarse_j1_v1", 1, 1, 1, (96, 72), (24, 18), syn.SPACE_SIZE, center_list, (5, 7, 3), seed=3)
+    # augmented: rotation / scale / flip per sample, SSV-style fp32 cameras
+    run_project("unproj_coarse_aug", 3, 4, 5, (192, 144), (48, 36), syn.SPACE_SIZE, center_list, (12, 12, 6),
+                seed=5, rotations=[0.0, 30.0, -30.0], scale_mults=[1.0, 1.3, 0.8], flip=[False, True, True],
+                ssv_style=True)
+    # fine grid: per-sample centres (B,5), one invalid row (flag < 0)
+    gc = np.array([[300.0, -800.0, 900.0, 0.0, 0.9],
+                   [0.0, 0.0, 0.0, -1.0, 0.1],
+                   [-1200.0, 400.0, 1000.0, 2.0, 0.7]], np.float32)
+    run_project("unproj_fine_small", 3, 5, 3, (384, 288), (96, 72), syn.FINE_GRID_SIZE, gc, (16, 16, 16), seed=7,
+                hm_kind="people")
+    # gradient golden (autograd through the reference path), random + flip/rot
+    run_project("unproj_grad_small", 2, 3, 3, (96, 72), (24, 18), syn.SPACE_SIZE, center_list, (10, 10, 5), seed=9,
+                with_grad=True)
+    gcg = np.array([[300.0, -800.0, 900.0, 0.0, 0.9], [-500.0, 200.0, 1000.0, 1.0, 0.9]], np.float32)
+    run_project("unproj_grad_fine_aug", 2, 3, 2, (192, 144), (48, 36), syn.FINE_GRID_SIZE, gcg, (12, 12, 12), seed=13,
+                rotations=[15.0, -20.0], scale_mults=[1.1, 0.9], flip=[True, False], ssv_style=True,
+                with_grad=True)
+    # full-size configs: sub-sampled outputs + float64 sums
+    run_project("unproj_coarse_full_96x72", 1, 5, 15, (384, 288), (96, 72), syn.SPACE_SIZE, center_list,
+                syn.INITIAL_CUBE_SIZE, store="sub", stride=37)
+    run_project("unproj_coarse_full_240x128", 1, 5, 15, (960, 512), (240, 128), syn.SPACE_SIZE, center_list,
+                syn.INITIAL_CUBE_SIZE, store="sub", stride=37, seed=1)
+    gcf = np.array([[300.0, -800.0, 900.0, 0.0, 0.9]], np.float32)
+    run_project("unproj_fine_full_240x128", 1, 5, 15, (960, 512), (240, 128), syn.FINE_GRID_SIZE, gcf,
+                syn.FINE_CUBE_SIZE, store="sub", stride=101, seed=2)
+    run_project("unproj_stress_v10", 1, 10, 15, (960, 512), (240, 128), syn.SPACE_SIZE, center_list,
+                (160, 160, 40), store="sub", stride=397, seed=4)
+
+    # ------------------------------------------------------------------ nms / proposals (a15,a16)
+    cubes_p, _, _, _ = run_project("unproj_people_coarse", 2, 5, 15, (384, 288), (96, 72), syn.SPACE_SIZE,
+                                   center_list, syn.INITIAL_CUBE_SIZE, hm_kind="people", seed=21, store="sub",
+                                   stride=53)
+    root = cubes_p[:, 2].contiguous()
+    vals, idx = nms(root, 10)
+    rng = np.random.default_rng(31)
+    rnd = torch.from_numpy(rng.random((3, 16, 12, 8), dtype=np.float32))
+    vals_r, idx_r = nms(rnd, 10)
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), people_vals=vals.numpy(), people_idx=idx.numpy(),
+                        rnd_seed=31, rnd_shape=np.array([3, 16, 12, 8]), rnd_vals=vals_r.numpy(),
+                        rnd_idx=idx_r.numpy())
+    print("nms people vals", vals[0].numpy())
+
+    # ------------------------------------------------------------------ V2V + root net + pose net (a13,a14,a17,a18)
+    J = 4
+    v2v = V2VNet(J, 1)
+    syn.fill_parameters_deterministic(v2v, seed=41, scale=0.05)
+    v2v.eval()
+    xin = torch.from_numpy(np.random.default_rng(43).random((2, J, 16, 16, 8), dtype=np.float32))
+    with torch.no_grad():
+        y = v2v(xin)
+    np.savez_compressed(os.path.join(HERE, "v2v.npz"), in_seed=43, in_shape=np.array(xin.shape), param_seed=41,
+                        param_scale=0.05, out=y.numpy(), keys=np.array(sorted(v2v.state_dict().keys())))
+    print("v2v out", y.shape, float(y.abs().max()))
+
+    img, hm = (384, 288), (96, 72)
+    cfg = make_cfg(img, hm, syn.SPACE_SIZE, syn.SPACE_CENTER, (24, 24, 8), syn.FINE_GRID_SIZE, (16, 16, 16), J,
+                   threshold=0.0)
+    B, V = 2, 4
+    meta = syn.make_meta(B, V, img)
+    hms, _ = syn.people_heatmaps(B, V, J, hm[1], hm[0], img, seed=51)
+    rootnet = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(rootnet, seed=53, scale=0.05)
+    rootnet.eval()
+    posenet = PoseRegressionNet(cfg)
+    syn.fill_parameters_deterministic(posenet, seed=55, scale=0.05)
+    posenet.eval()
+    with torch.no_grad():
+        root_cubes, grid_centers = rootnet(hms, meta)
+        preds = []
+        for n in range(3):
+            preds.append(posenet(hms, meta, grid_centers[:, n]).numpy())
+    np.savez_compressed(os.path.join(HERE, "rootnet_posenet.npz"), B=B, V=V, J=J, img=np.array(img), hm=np.array(hm),
+                        cube=np.array([24, 24, 8]), fine_cube=np.array([16, 16, 16]), hm_seed=51,
+                        root_seed=53, pose_seed=55, param_scale=0.05, threshold=0.0,
+                        root_cubes=root_cubes.numpy(), grid_centers=grid_centers.numpy(), preds=np.stack(preds),
+                        root_keys=np.array(sorted(rootnet.state_dict().keys())),
+                        pose_keys=np.array(sorted(posenet.state_dict().keys())))
+    print("rootnet grid_centers[0,:3]", grid_centers[0, :3].numpy())
+    print("posenet pred[0][0,:2]", preds[0][0, :2])
+
+
+if __name__ == "__main__":
+    main()
