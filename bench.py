@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the SelfPose3d root-localisation hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on):
+  Panoptic 5-view `CuboidProposalNet` forward-only, batch 4 per GPU: 5 x (4,15,128,240) heat-maps
+  (960x512 network input, YAML-native) resident in HBM -> unprojection into the 80x80x20 grid
+  (HIP kernels) -> V2V 3D conv stack (PyTorch-ROCm/MIOpen, fp32) -> fused NMS/top-k (HIP).
+  One "step" = one such forward over one batch.  Multi-GPU = one process per GPU, frames sharded
+  by rank (weak scaling), NO data-path collective (the path is embarrassingly parallel over frames).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the unprojection kernel: algorithmic bytes / HIP-event time vs 8 TB/s HBM peak
+  cpu_baseline - the CPU oracle (scalar C port) + torch-CPU V2V on a bounded sample of the same workload
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (configs[1]: 4)")
+    ap.add_argument("--roofline-iters", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=3)
+    ap.add_argument("--cold", action="store_true", help="also time the kernel rotating >256 MiB of inputs (MALL-cold)")
+    return ap.parse_args()
+
+
+def build_workload(batch, rank, dev):
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+
+    cfg = load_config(None)                         # Panoptic 5-cam defaults == the reference YAML
+    V, J = int(cfg.DATASET.CAMERA_NUM), int(cfg.NETWORK.NUM_JOINTS)
+    w, h = cfg.NETWORK.HEATMAP_SIZE
+    meta = syn.make_meta(batch, V, cfg.NETWORK.IMAGE_SIZE)          # CPU tensors, as a DataLoader emits
+    hms = [x.to(dev) for x in syn.random_heatmaps(batch, V, J, h, w, seed=1000 + rank)]
+    torch.manual_seed(0)
+    model = CuboidProposalNet(cfg).eval().to(dev)
+    return cfg, meta, hms, model
+
+
+def event_time_ms(fn, iters, dev):
+    """average duration of fn() launched back-to-back on torch's current stream (HIP events)"""
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
+    from selfpose3d_amd import _lib
+    B, J, h, w = hms[0].shape
+    V = len(hms)
+    pl = model.project_layer
+    cam = pl.camera_table(meta, B, None, dev)
+    centers, valid = pl.centers_valid([model.grid_center], B, dev)
+    cube, gs, img = model.cube_size, model.grid_size, pl.img_size
+    N = cube[0] * cube[1] * cube[2]
+    packed = _lib.pack_heatmaps(hms, jp=16)
+    views = [packed[c] for c in range(V)]
+
+    def k_nhwc():
+        _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False)
+
+    def k_planar():
+        _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
+
+    def k_pack():
+        _lib.pack_heatmaps(hms, jp=16, out=packed)
+
+    t_nhwc = event_time_ms(k_nhwc, iters, dev)
+    t_planar = event_time_ms(k_planar, max(10, iters // 10), dev)
+    t_pack = event_time_ms(k_pack, iters, dev)
+    # algorithmic bytes per launch: read every heat-map element once, write cubes
+    # once; `grids` is not requested by the root net so its 3N term is dropped.
+    alg_bytes = 4.0 * B * (V * J * h * w + J * N)
+    achieved = alg_bytes / (t_nhwc * 1e-3) / 1e9
+    out = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "sp3d::unproject_nhwc_kernel<16,true,2>", "kernel_us": round(t_nhwc * 1e3, 2),
+        "algorithmic_bytes": int(alg_bytes),
+        "other_kernels_us": {"pack_nhwc_kernel<16>": round(t_pack * 1e3, 2),
+                             "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},
+        "timing": f"HIP events on the launch stream, {iters} back-to-back launches, inputs L2/MALL-warm",
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("workload") == f"B{B}_V{V}_J{J}_{w}x{h}_{cube[0]}x{cube[1]}x{cube[2]}":
+                out["traffic"] = rec.get("hbm_bytes_per_launch")
+                out["traffic_source"] = rec.get("source")
+        except Exception:
+            pass
+    if cold:
+        nset = 8
+        sets = [_lib.pack_heatmaps([torch.rand_like(x) for x in hms], jp=16) for _ in range(nset)]
+        state = {"i": 0}
+
+        def k_cold():
+            p = sets[state["i"] % nset]
+            state["i"] += 1
+            _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube,
+                               gs, img, False)
+        out["kernel_us_rotating_inputs"] = round(event_time_ms(k_cold, iters, dev) * 1e3, 2)
+    return out
+
+
+def cpu_baseline_leg(cfg, meta, hms, model, reps):
+    """CPU port of the same step on the host cores of this box: scalar C oracle for the unprojection
+    and NMS (1 thread) + the V2V stack on torch-CPU pinned to 1 thread.  Bounded sample: `reps`
+    batches of the bench workload.  This is the checker's code timed as a baseline - it is never
+    on the product path."""
+    from oracle import oracle
+    from selfpose3d_amd.camera_pack import pack_cameras
+    B = hms[0].shape[0]
+    V = len(hms)
+    pl = model.project_layer
+    cam = pack_cameras(meta, B, pl.img_size)
+    centers = np.repeat(np.asarray([model.grid_center], np.float32), B, 0)
+    valid = np.ones(B, np.uint8)
+    hnp = [x.cpu().numpy() for x in hms]
+    import copy
+    v2v = copy.deepcopy(model.v2v_net).cpu().eval()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cubes, _ = oracle.unproject_fwd(hnp, cam, centers, valid, model.grid_size, model.cube_size, pl.img_size,
+                                        want_grids=False)
+        with torch.no_grad():
+            root = v2v(torch.from_numpy(cubes)).squeeze(1).numpy()
+        oracle.nms_topk(np.ascontiguousarray(root), 10)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(nthr)
+    return {"value": round(reps * B / dt, 4), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} batches of {B} frames of the bench workload ({dt:.1f} s): oracle/sp3d_oracle.c "
+                      f"unprojection + NMS (scalar C) and torch-CPU V2V, 1 thread",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the unprojection path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    torch.backends.cudnn.benchmark = True
+    cfg, meta, hms, model = build_workload(args.batch, rank, dev)
+
+    def step():
+        with torch.no_grad():
+            return model(hms, meta)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        B = args.batch
+        V, J = len(hms), hms[0].shape[1]
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "multi-view samples/sec (5-view Panoptic, 80x80x20 voxel)",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "panoptic_5view_cuboid_proposal_net_fwd_b4 (BASELINE configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
+                       "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
+                       "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
+                       "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(MIOpen fp32) -> NMS/top-k(HIP)"},
+            "views_x_frames_per_s": round(value * V, 3),
+        }
+        result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, cold=args.cold)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_leg(cfg, meta, hms, model, args.cpu_baseline_reps)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/*
+ * sp3d.h - C ABI of libsp3d.so: the MI355X (gfx950) implementation of SelfPose3d's
+ * multi-view heat-map -> voxel unprojection hot path.
+ *
+ * The reference has no FFI / operator registry: its seam is the Python module
+ * `ProjectLayer` (/root/reference/lib/models/project_layer.py:15-106), constructed at
+ * lib/models/cuboid_proposal_net.py:95, cuboid_proposal_net_soft.py:83,
+ * pose_regression_net.py:37.  These entry points are what a binding for that seam (and for
+ * the two small reductions either side of it) calls; `selfpose3d_amd/project_layer.py` is
+ * the ctypes binding, INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer except `hm_views` (a HOST array of V
+ *     device pointers) and `grid_size` (host) is a DEVICE pointer valid on `stream`'s device;
+ *   - the library allocates nothing, keeps no global state, never synchronises the host;
+ *     work is enqueued on `stream` (a hipStream_t, NULL = default stream) and is
+ *     HIP-graph capturable;
+ *   - every output buffer is fully overwritten (no pre-zeroing needed) unless noted;
+ *   - return 0 on success, a negative SP3D_E* for bad arguments, a positive hipError_t if a
+ *     launch failed.  Nothing throws across this boundary.
+ */
+#ifndef SP3D_H
+#define SP3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP3D_ABI_VERSION 1
+#define SP3D_MAX_VIEWS 16
+#define SP3D_MAX_TOPK 32
+
+/* packed per-(sample, view) camera record: fp32[SP3D_CAM_STRIDE], table shape (B, V, 32).
+ * Built on the host by selfpose3d_amd/camera_pack.py::pack_cameras (one upload per call,
+ * replacing lib/models/project_layer.py:64-75 + lib/utils/cameras.py:13-24 +
+ * lib/utils/transforms.py:61-103 executed per (sample, view) in the reference). */
+#define SP3D_CAM_STRIDE 32
+#define SP3D_CAM_R 0      /* [9]  world->camera rotation, row-major            cameras.py:14 */
+#define SP3D_CAM_T 9      /* [3]  camera centre in world, mm  (Xc = R (X - T)) cameras.py:15 */
+#define SP3D_CAM_F 12     /* [2]  fx, fy                                      cameras.py:16-18 */
+#define SP3D_CAM_C 14     /* [2]  cx, cy                                      cameras.py:19-21 */
+#define SP3D_CAM_K 16     /* [3]  radial k0,k1,k2                             cameras.py:22 */
+#define SP3D_CAM_P 19     /* [2]  tangential p0,p1                            cameras.py:23 */
+#define SP3D_CAM_A 21     /* [6]  2x3 crop affine, original image -> network input, row-major
+                                  (fp32 cast of get_affine_transform, project_layer.py:69-72) */
+#define SP3D_CAM_W0 27    /* original image width  = 2*center.x  (project_layer.py:68) */
+#define SP3D_CAM_H0 28    /* original image height = 2*center.y */
+#define SP3D_CAM_FLIP 29  /* 1.0 if flip_xcoords[b] else 0.0      (project_layer.py:82) */
+
+enum {
+    SP3D_OK = 0,
+    SP3D_EINVAL = -1,        /* a dimension <= 0, V > SP3D_MAX_VIEWS, unknown layout ...  */
+    SP3D_ENULL = -2,         /* a required pointer is NULL                                */
+    SP3D_ERANGE = -3,        /* X*Y*Z, B*J*N or the launch grid overflows 32-bit limits   */
+    SP3D_EUNSUPPORTED = -4   /* combination not implemented (e.g. Jp not a multiple of 4) */
+};
+
+/* heat-map layouts accepted by the unprojection kernels (per-view pointers in both) */
+enum {
+    SP3D_LAYOUT_PLANAR = 0,  /* view c: (B, J, h, w) fp32 - the reference's layout (pose_resnet.py:203) */
+    SP3D_LAYOUT_NHWC = 1     /* view c: (B, h, w, Jp) fp32, Jp%4==0, channels >= J are ignored padding */
+};
+
+int sp3d_abi_version(void);
+const char *sp3d_error_string(int code);
+
+/*
+ * Re-tile V planar heat-maps (B,J,h,w) into ONE channels-last buffer packed[(V,B,h,w,Jp)],
+ * channels J..Jp-1 zero-filled, so that one bilinear tap is a single Jp*4-byte read.
+ * (Input side of ProjectLayer.get_voxel: the `heatmaps` list, project_layer.py:42-44.)
+ */
+int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V, int J, int Jp, int h, int w,
+                       void *stream);
+
+/*
+ * ProjectLayer.get_voxel forward (project_layer.py:42-102; math: DESIGN.md §3).
+ *   hm_views  HOST array of V device pointers, layout per `hm_layout` (Jp used for NHWC only)
+ *   cam       (B,V,32) camera table            centers (B,3) grid centres, mm
+ *   valid     (B) uint8; 0 => sample skipped: its cubes/grids rows are written as zeros
+ *             (project_layer.py:48,51,54: `grid_center[i][3] >= 0`)
+ *   cubes     (B,J,X,Y,Z) fp32, z fastest       grids (B,X*Y*Z,3) fp32 or NULL (not wanted)
+ *   grid_size HOST float[3] box edge lengths mm; W_in,H_in network input size (cfg IMAGE_SIZE)
+ */
+int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam, const float *centers,
+                       const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w, int X,
+                       int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream);
+
+/*
+ * Gradient of get_voxel w.r.t. the heat-maps (autograd of project_layer.py:93-99;
+ * cameras/grids never need gradients: proposals are detached, cuboid_proposal_net.py:57-59).
+ *   hm_views      planar heat-maps of the forward pass (needed for the clamp mask)
+ *   grad_cubes    (B,J,X,Y,Z)
+ *   grad_hm_views HOST array of V device pointers (B,J,h,w); MUST be zero-filled by the
+ *                 caller: the kernel accumulates with atomics (summation order is therefore
+ *                 not deterministic; bounded by fp32 rounding).
+ */
+int sp3d_unproject_bwd(const float *const *hm_views, const float *cam, const float *centers, const uint8_t *valid,
+                       const float *grad_cubes, float *const *grad_hm_views, int B, int V, int J, int h, int w,
+                       int X, int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream);
+
+/*
+ * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,
+ * lib/models/cuboid_proposal_net.py:42-52): 3x3x3 local-max mask, top-k over the flat volume
+ * (ties: larger value, then LOWER flat index), unravel, index -> mm.
+ *   root_cubes (B,X,Y,Z)   vals (B,k) fp32   idx (B,k,3) int64   locs (B,k,3) fp32 mm or NULL
+ *   workspace  device scratch of sp3d_nms_topk_workspace_bytes(...) bytes
+ */
+int64_t sp3d_nms_topk_workspace_bytes(int B, int X, int Y, int Z, int k);
+int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
+                  const float *grid_center, float *vals, int64_t *idx, float *locs, void *workspace, void *stream);
+
+/*
+ * SoftArgmaxLayer.forward (lib/models/pose_regression_net.py:19-28):
+ *   out[b,j,:] = sum_n softmax(beta * x[b,j,:])[n] * grids[b,n,:]
+ *   x (Bv,J,N)   grids (Bv,N,3)   out (Bv,J,3)
+ */
+int sp3d_soft_argmax(const float *x, const float *grids, float *out, int Bv, int J, int64_t N, float beta,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SP3D_H */

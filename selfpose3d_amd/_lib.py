@@ -1,0 +1,186 @@
+"""ctypes binding of libsp3d.so (C ABI: include/sp3d.h).
+
+There is NO CPU fallback behind this module: if the library is missing or a call fails,
+an exception is raised.  torch is used only to obtain device pointers and the current HIP
+stream (``torch.cuda.current_stream().cuda_stream``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsp3d.so")
+
+LAYOUT_PLANAR = 0
+LAYOUT_NHWC = 1
+MAX_VIEWS = 16
+MAX_TOPK = 32
+ABI_VERSION = 1
+
+EXPORTS = [
+    "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
+    "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax",
+]
+
+_lib = None
+
+
+class Sp3dError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsp3d.so (building nothing: run `python -m selfpose3d_amd.build` first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Sp3dError(
+            f"{LIB_PATH} not found - the HIP extension is not built. Run `python -m selfpose3d_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the unprojection path.")
+    lib = C.CDLL(LIB_PATH)
+    P, I, F, V = C.c_void_p, C.c_int, C.c_float, C.c_void_p
+    lib.sp3d_abi_version.restype = I
+    lib.sp3d_error_string.restype = C.c_char_p
+    lib.sp3d_error_string.argtypes = [I]
+    lib.sp3d_pack_heatmaps.restype = I
+    lib.sp3d_pack_heatmaps.argtypes = [P, P, I, I, I, I, I, I, V]
+    lib.sp3d_unproject_fwd.restype = I
+    lib.sp3d_unproject_fwd.argtypes = [P, I, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_unproject_bwd.restype = I
+    lib.sp3d_unproject_bwd.argtypes = [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_nms_topk_workspace_bytes.restype = C.c_int64
+    lib.sp3d_nms_topk_workspace_bytes.argtypes = [I, I, I, I, I]
+    lib.sp3d_nms_topk.restype = I
+    lib.sp3d_nms_topk.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, V]
+    lib.sp3d_soft_argmax.restype = I
+    lib.sp3d_soft_argmax.argtypes = [P, P, P, I, I, C.c_int64, F, V]
+    if hasattr(lib, "sp3d_unproject_fwd_variant"):
+        lib.sp3d_unproject_fwd_variant.restype = I
+        lib.sp3d_unproject_fwd_variant.argtypes = [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, V]
+    if lib.sp3d_abi_version() != ABI_VERSION:
+        raise Sp3dError(f"libsp3d.so ABI {lib.sp3d_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sp3d_error_string(rc).decode()
+        raise Sp3dError(f"{what} failed: {msg} (code {rc})")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise Sp3dError(f"{name} must live on the GPU (got {t.device}); the unprojection path has no CPU fallback")
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _f3(vals):
+    return (C.c_float * 3)(float(vals[0]), float(vals[1]), float(vals[2]))
+
+
+def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """list[V] of (B,J,h,w) fp32 contiguous -> (V,B,h,w,jp) channels-last, padded channels zero."""
+    lib = load()
+    h0 = hms[0]
+    _require_cuda(h0, "heatmaps")
+    B, J, h, w = h0.shape
+    V = len(hms)
+    hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
+    if out is None:
+        out = torch.empty((V, B, h, w, jp), dtype=torch.float32, device=h0.device)
+    check(lib.sp3d_pack_heatmaps(_ptr_array(hms), out.data_ptr(), B, V, J, jp, h, w, _stream(h0.device)),
+          "sp3d_pack_heatmaps")
+    return out
+
+
+def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
+                  valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
+                  want_grids: bool = True, variant: Optional[int] = None):
+    lib = load()
+    dev = cam.device
+    _require_cuda(cam, "cam")
+    X, Y, Z = (int(c) for c in cube_size)
+    V = len(views)
+    cubes = torch.empty((B, J, X, Y, Z), dtype=torch.float32, device=dev)
+    grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
+    gs = _f3(grid_size)
+    if variant is None:
+        rc = lib.sp3d_unproject_fwd(_ptr_array(views), layout, jp, cam.data_ptr(), centers.data_ptr(),
+                                    valid.data_ptr(), cubes.data_ptr(), grids.data_ptr() if want_grids else None,
+                                    B, V, J, h, w, X, Y, Z, gs, int(img_size[0]), int(img_size[1]), _stream(dev))
+    else:
+        assert layout == LAYOUT_NHWC
+        rc = lib.sp3d_unproject_fwd_variant(_ptr_array(views), jp, cam.data_ptr(), centers.data_ptr(),
+                                            valid.data_ptr(), cubes.data_ptr(),
+                                            grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
+                                            int(img_size[0]), int(img_size[1]), int(variant), _stream(dev))
+    check(rc, "sp3d_unproject_fwd")
+    return cubes, grids
+
+
+def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: torch.Tensor, cube_size, grid_size,
+                  img_size):
+    lib = load()
+    dev = cam.device
+    B, J, h, w = hms[0].shape
+    X, Y, Z = (int(c) for c in cube_size)
+    V = len(hms)
+    grad_cubes = grad_cubes.contiguous().float()
+    grads = torch.zeros((V, B, J, h, w), dtype=torch.float32, device=dev)
+    gviews = [grads[c] for c in range(V)]
+    rc = lib.sp3d_unproject_bwd(_ptr_array(hms), cam.data_ptr(), centers.data_ptr(), valid.data_ptr(),
+                                grad_cubes.data_ptr(), _ptr_array(gviews), B, V, J, h, w, X, Y, Z, _f3(grid_size),
+                                int(img_size[0]), int(img_size[1]), _stream(dev))
+    check(rc, "sp3d_unproject_bwd")
+    return gviews
+
+
+def nms_topk(root_cubes: torch.Tensor, k: int, grid_size=None, grid_center=None):
+    """(B,X,Y,Z) -> vals (B,k) fp32, idx (B,k,3) int64, locs (B,k,3) fp32 mm (None without grid_size)."""
+    lib = load()
+    _require_cuda(root_cubes, "root_cubes")
+    rc_ = root_cubes.contiguous().float()
+    B, X, Y, Z = rc_.shape
+    dev = rc_.device
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, k, 3), dtype=torch.int64, device=dev)
+    locs = torch.empty((B, k, 3), dtype=torch.float32, device=dev) if grid_size is not None else None
+    nbytes = lib.sp3d_nms_topk_workspace_bytes(B, X, Y, Z, k)
+    ws = torch.empty((max(int(nbytes), 8),), dtype=torch.uint8, device=dev)
+    rc = lib.sp3d_nms_topk(rc_.data_ptr(), B, X, Y, Z, k, _f3(grid_size) if grid_size is not None else None,
+                           _f3(grid_center) if grid_center is not None else None, vals.data_ptr(), idx.data_ptr(),
+                           locs.data_ptr() if locs is not None else None, ws.data_ptr(), _stream(dev))
+    check(rc, "sp3d_nms_topk")
+    return vals, idx, locs
+
+
+def soft_argmax(x: torch.Tensor, grids: torch.Tensor, beta: float) -> torch.Tensor:
+    """x (Bv,J,X,Y,Z) or (Bv,J,N); grids (Bv,N,3) -> (Bv,J,3)"""
+    lib = load()
+    _require_cuda(x, "x")
+    Bv, J = x.shape[:2]
+    xc = x.contiguous().float().reshape(Bv, J, -1)
+    N = xc.shape[2]
+    gc = grids.contiguous().float()
+    out = torch.empty((Bv, J, 3), dtype=torch.float32, device=x.device)
+    if Bv == 0:
+        return out
+    check(lib.sp3d_soft_argmax(xc.data_ptr(), gc.data_ptr(), out.data_ptr(), Bv, J, N, float(beta), _stream(x.device)),
+          "sp3d_soft_argmax")
+    return out

@@ -1,0 +1,44 @@
+"""Build libsp3d.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m selfpose3d_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  hipcc
+cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip"]
+HEADERS = ["sp3d_device.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
+LIB = os.path.join(HERE, "libsp3d.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,17 @@
+/* sp3d_tuning.h - measurement-only entry points of libsp3d.so (NOT part of the drop-in ABI
+ * in include/sp3d.h).  Used by tools/ab_variants.py for within-process A/B of kernel variants. */
+#ifndef SP3D_TUNING_H
+#define SP3D_TUNING_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable XCD-aware tile map */
+int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float *cam, const float *centers,
+                               const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w,
+                               int X, int Y, int Z, const float *grid_size, int W_in, int H_in, int variant,
+                               void *stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

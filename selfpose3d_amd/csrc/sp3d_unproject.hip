@@ -1,0 +1,571 @@
+// sp3d_unproject.hip - gfx950 kernels for ProjectLayer.get_voxel (forward, backward) and the
+// heat-map re-tiling pass, plus their C-ABI entry points (include/sp3d.h).
+//
+// Reference path: /root/reference/lib/models/project_layer.py:42-102 and its helpers
+// lib/utils/cameras.py:27-55, lib/utils/transforms.py:119-123.  The reference runs this as a
+// Python batch x view loop of ~90 tiny kernels; here one launch covers the whole batch.
+//
+// Kernels
+//   unproject_planar_kernel  lane = voxel, heat-maps in the reference's planar (B,J,h,w)
+//                            layout; simple, exact, gather of 4*J scattered dwords / view.
+//   pack_nhwc_kernel         (B,J,h,w) x V  ->  (V,B,h,w,Jp): LDS-tiled transpose so that a
+//                            bilinear tap becomes ONE contiguous Jp*4-byte read.
+//   unproject_nhwc_kernel    the fast path: phase 1 (lane = voxel) projects the tile's
+//                            voxels through every camera and stages the sample positions in
+//                            LDS; phase 2 (4 lanes = one voxel, each lane one 16-byte channel
+//                            quad) gathers the taps with dwordx4 loads whose 4-lane groups
+//                            read 64 contiguous bytes; phase 3 stores the (J, tile) result
+//                            through LDS as coalesced dwordx4 rows.
+//   unproject_bwd_kernel     recomputes the forward value (clamp mask) and scatters
+//                            g * w_tap with hardware fp32 atomics.
+#include "sp3d_device.h"
+
+namespace sp3d {
+
+constexpr int TILE = 256; // voxels per workgroup (= threads per workgroup)
+
+// ------------------------------------------------------------------------------------------
+// planar-layout forward: lane = voxel.  JC = channels accumulated per pass.
+// ------------------------------------------------------------------------------------------
+template <int JC>
+__global__ __launch_bounds__(TILE) void unproject_planar_kernel(Views hm, const float *__restrict__ cam,
+                                                               const float *__restrict__ centers,
+                                                               const uint8_t *__restrict__ valid,
+                                                               float *__restrict__ cubes, float *__restrict__ grids,
+                                                               Geom g)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * TILE + threadIdx.x;
+    if (n >= g.N) return;
+    float *cb = cubes + (size_t)b * g.J * g.N;
+    if (!valid[b]) { // project_layer.py:48,51,54 - skipped sample stays zero
+        for (int j = 0; j < g.J; ++j) cb[(size_t)j * g.N + n] = 0.0f;
+        if (grids) {
+            float *gp = grids + ((size_t)b * g.N + n) * 3;
+            gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+        }
+        return;
+    }
+    const int vx = n / g.YZ, rem = n - vx * g.YZ, vy = rem / g.Z, vz = rem - vy * g.Z;
+    const float x = linspace_at(g.Lx, g.X, vx) + centers[3 * b + 0];
+    const float y = linspace_at(g.Ly, g.Y, vy) + centers[3 * b + 1];
+    const float z = linspace_at(g.Lz, g.Z, vz) + centers[3 * b + 2];
+    if (grids) {
+        float *gp = grids + ((size_t)b * g.N + n) * 3;
+        gp[0] = x; gp[1] = y; gp[2] = z;
+    }
+    const float W_in = (float)g.W_in, H_in = (float)g.H_in;
+    const size_t plane = (size_t)g.h * g.w;
+    for (int j0 = 0; j0 < g.J; j0 += JC) {
+        float acc[JC];
+#pragma unroll
+        for (int k = 0; k < JC; ++k) acc[k] = 0.0f;
+        float cnt = 0.0f;
+        bool bad = false;
+        for (int c = 0; c < g.V; ++c) {
+            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            float ix, iy;
+            const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
+            cnt += bound ? 1.0f : 0.0f;
+            if (ix != ix || iy != iy) { bad = true; continue; } // NaN sample -> NaN -> 0 (project_layer.py:98)
+            if (!bound) continue;                                // val * 0
+            const Bilin bl = bilin(ix, iy);
+            const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
+            const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
+            const float *base = hm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+#pragma unroll
+            for (int k = 0; k < JC; ++k) {
+                if (j0 + k < g.J) {
+                    const float *pl = base + (size_t)k * plane;
+                    const float t00 = (x0ok && y0ok) ? pl[0] : 0.0f;
+                    const float t10 = (x1ok && y0ok) ? pl[1] : 0.0f;
+                    const float t01 = (x0ok && y1ok) ? pl[g.w] : 0.0f;
+                    const float t11 = (x1ok && y1ok) ? pl[g.w + 1] : 0.0f;
+                    float v = t00 * bl.wnw;
+                    v = fmaf(t10, bl.wne, v);
+                    v = fmaf(t01, bl.wsw, v);
+                    v = fmaf(t11, bl.wse, v);
+                    acc[k] = acc[k] + v;
+                }
+            }
+        }
+        const float den = cnt + 1e-6f;
+#pragma unroll
+        for (int k = 0; k < JC; ++k)
+            if (j0 + k < g.J) cb[(size_t)(j0 + k) * g.N + n] = bad ? 0.0f : fuse(acc[k], den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// (B,J,h,w) x V  ->  (V,B,h,w,JP) re-tiling.  One workgroup = 256 pixels of one (view,sample).
+// ------------------------------------------------------------------------------------------
+constexpr int PSTR = 260; // LDS row stride (floats): rows 16-B aligned, <=2-way write conflicts
+
+template <int JP>
+__global__ __launch_bounds__(256) void pack_nhwc_kernel(Views hm, float *__restrict__ packed, int B, int J, int HW)
+{
+    __shared__ float tile[JP][PSTR];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * 256;
+    const int b = blockIdx.y, v = blockIdx.z;
+    const float *src = hm.p[v] + (size_t)b * J * HW;
+    const int p = p0 + tid;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+        float val = 0.0f;
+        if (j < J && p < HW) val = src[(size_t)j * HW + p];
+        tile[j][tid] = val;
+    }
+    __syncthreads();
+    constexpr int NQ = JP / 4;
+    float *dst = packed + (((size_t)v * B + b) * HW + p0) * JP;
+    for (int e = tid; e < 256 * NQ; e += 256) {
+        const int px = e / NQ, q = e - px * NQ;
+        if (p0 + px < HW) {
+            float4 o;
+            o.x = tile[4 * q + 0][px]; o.y = tile[4 * q + 1][px];
+            o.z = tile[4 * q + 2][px]; o.w = tile[4 * q + 3][px];
+            *reinterpret_cast<float4 *>(dst + (size_t)px * JP + 4 * q) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// channels-last forward (the hot kernel).
+//   JP   = floats per pixel (channel stride), multiple of 4, <= 16 per pass
+//   LDS  = sIx,sIy [V][TILE] sample positions, sMask[TILE] bound bits (+bit31 NaN flag),
+//          sOut [JP][OSTR] result tile
+// ------------------------------------------------------------------------------------------
+constexpr int OSTR = 260;
+
+template <int JP, bool XCD, int U>
+__global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const float *__restrict__ cam,
+                                                             const float *__restrict__ centers,
+                                                             const uint8_t *__restrict__ valid,
+                                                             float *__restrict__ cubes, float *__restrict__ grids,
+                                                             Geom g, int tiles_per_sample, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sOut = smem;                                   // [JP][OSTR]
+    float *sIx = sOut + JP * OSTR;                        // [V][TILE]
+    float *sIy = sIx + g.V * TILE;                        // [V][TILE]
+    uint32_t *sMask = reinterpret_cast<uint32_t *>(sIy + g.V * TILE); // [TILE]
+
+    int lt = blockIdx.x;
+    if (XCD) {
+        lt = xcd_remap(blockIdx.x, total_tiles);
+        if (lt >= total_tiles) return;
+    }
+    const int b = lt / tiles_per_sample;
+    const int n0 = (lt - b * tiles_per_sample) * TILE;
+    const int tid = threadIdx.x;
+    const int nvox = min(TILE, g.N - n0);
+    float *cb = cubes + (size_t)b * g.J * g.N;
+    constexpr int NQ = JP / 4;
+
+    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        for (int j = 0; j < g.J; ++j)
+            if (tid < nvox) cb[(size_t)j * g.N + n0 + tid] = 0.0f;
+        if (grids && tid < nvox) {
+            float *gp = grids + ((size_t)b * g.N + n0 + tid) * 3;
+            gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+        }
+        return;
+    }
+
+    // ---- phase 1: lane = voxel; project through every camera, stage sample positions
+    {
+        const int n = n0 + tid;
+        uint32_t mask = 0;
+        if (tid < nvox) {
+            const int vx = n / g.YZ, rem = n - vx * g.YZ, vy = rem / g.Z, vz = rem - vy * g.Z;
+            const float x = linspace_at(g.Lx, g.X, vx) + centers[3 * b + 0];
+            const float y = linspace_at(g.Ly, g.Y, vy) + centers[3 * b + 1];
+            const float z = linspace_at(g.Lz, g.Z, vz) + centers[3 * b + 2];
+            if (grids) {
+                float *gp = grids + ((size_t)b * g.N + n) * 3;
+                gp[0] = x; gp[1] = y; gp[2] = z;
+            }
+            const float W_in = (float)g.W_in, H_in = (float)g.H_in;
+            for (int c = 0; c < g.V; ++c) {
+                const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+                float ix, iy;
+                const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
+                if (bound) mask |= (1u << c);
+                if (ix != ix || iy != iy) mask |= 0x80000000u;
+                sIx[c * TILE + tid] = ix;
+                sIy[c * TILE + tid] = iy;
+            }
+        }
+        sMask[tid] = mask;
+    }
+    __syncthreads();
+
+    // ---- phase 2: 4 lanes = one voxel; lane q owns channels [4q, 4q+4).  U voxels are in
+    //      flight per lane (4*U dwordx4 loads issued back to back before the first use).
+    {
+        constexpr int LPV = 4;                 // lanes per voxel
+        constexpr int GROUPS = TILE / LPV;     // 64 voxel groups per workgroup
+        constexpr int VPG = TILE / GROUPS;     // 4 voxels per group
+        const int grp = tid / LPV, q = tid % LPV;
+        const bool qact = q < NQ;              // JP < 16: upper lanes idle
+        const size_t rowf = (size_t)g.w * JP;  // floats per heat-map row
+#pragma unroll 1
+        for (int i0 = 0; i0 < VPG; i0 += U) {
+            float acc[U][4];
+            uint32_t msk[U];
+            uint32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                msk[i] = sMask[(i0 + i) * GROUPS + grp];
+                if (msk[i] & 0x80000000u) msk[i] = 0x80000000u;   // NaN position: voxel is zero, skip gathers
+                any |= msk[i];
+                acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
+            }
+            uint32_t cnt[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) cnt[i] = sMask[(i0 + i) * GROUPS + grp];
+#pragma unroll 1
+            for (int c = 0; c < g.V; ++c) {
+                if (!__any((any >> c) & 1u)) continue;         // wave-uniform skip
+                const float *vb = hm.p[c] + (size_t)b * g.h * rowf + 4 * q;
+                float4 t00[U], t10[U], t01[U], t11[U];
+                float wnw[U], wne[U], wsw[U], wse[U];
+                // Branch-free gather: every lane always loads.  A tap outside the heat-map (zeros
+                // padding) or a lane whose voxel is not in view c gets weight 0 and a clamped /
+                // parked address (pixel (0,0): all parked lanes hit one cache line).
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const bool on = qact && ((msk[i] >> c) & 1u);
+                    const int t = (i0 + i) * GROUPS + grp;
+                    const Bilin bl = bilin(sIx[c * TILE + t], sIy[c * TILE + t]);
+                    const bool x0ok = on && bl.x0 >= 0 && bl.x0 <= g.w - 1;
+                    const bool x1ok = on && bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
+                    const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1;
+                    const bool y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
+                    wnw[i] = (x0ok && y0ok) ? bl.wnw : 0.0f;
+                    wne[i] = (x1ok && y0ok) ? bl.wne : 0.0f;
+                    wsw[i] = (x0ok && y1ok) ? bl.wsw : 0.0f;
+                    wse[i] = (x1ok && y1ok) ? bl.wse : 0.0f;
+                    const int xa = on ? min(max(bl.x0, 0), g.w - 1) : 0, xb = on ? min(max(bl.x0 + 1, 0), g.w - 1) : 0;
+                    const int ya = on ? min(max(bl.y0, 0), g.h - 1) : 0, yb = on ? min(max(bl.y0 + 1, 0), g.h - 1) : 0;
+                    const float *ra = vb + (size_t)ya * rowf, *rb = vb + (size_t)yb * rowf;
+                    t00[i] = *reinterpret_cast<const float4 *>(ra + xa * JP);
+                    t10[i] = *reinterpret_cast<const float4 *>(ra + xb * JP);
+                    t01[i] = *reinterpret_cast<const float4 *>(rb + xa * JP);
+                    t11[i] = *reinterpret_cast<const float4 *>(rb + xb * JP);
+                }
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    float v;
+                    v = t00[i].x * wnw[i]; v = fmaf(t10[i].x, wne[i], v); v = fmaf(t01[i].x, wsw[i], v); v = fmaf(t11[i].x, wse[i], v); acc[i][0] = acc[i][0] + v;
+                    v = t00[i].y * wnw[i]; v = fmaf(t10[i].y, wne[i], v); v = fmaf(t01[i].y, wsw[i], v); v = fmaf(t11[i].y, wse[i], v); acc[i][1] = acc[i][1] + v;
+                    v = t00[i].z * wnw[i]; v = fmaf(t10[i].z, wne[i], v); v = fmaf(t01[i].z, wsw[i], v); v = fmaf(t11[i].z, wse[i], v); acc[i][2] = acc[i][2] + v;
+                    v = t00[i].w * wnw[i]; v = fmaf(t10[i].w, wne[i], v); v = fmaf(t01[i].w, wsw[i], v); v = fmaf(t11[i].w, wse[i], v); acc[i][3] = acc[i][3] + v;
+                }
+            }
+            if (qact) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const int t = (i0 + i) * GROUPS + grp;
+                    const bool bad = (cnt[i] & 0x80000000u) != 0;
+                    const float den = (float)__popc(cnt[i] & 0x7fffffffu) + 1e-6f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sOut[(4 * q + k) * OSTR + t] = bad ? 0.0f : fuse(acc[i][k], den);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: coalesced store of the (J, tile) block, 16 B per lane where aligned
+    if (((g.N & 3) == 0) && nvox == TILE) {
+        for (int e = tid; e < g.J * (TILE / 4); e += TILE) {
+            const int j = e / (TILE / 4), u = e - j * (TILE / 4);
+            const float4 o = *reinterpret_cast<const float4 *>(&sOut[j * OSTR + 4 * u]);
+            *reinterpret_cast<float4 *>(cb + (size_t)j * g.N + n0 + 4 * u) = o;
+        }
+    } else {
+        for (int j = 0; j < g.J; ++j)
+            if (tid < nvox) cb[(size_t)j * g.N + n0 + tid] = sOut[j * OSTR + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: lane = voxel, planar layout.  Pass 1 recomputes the pre-clamp forward value (the
+// clamp mask: grad flows where 0 <= pre <= 1, torch.clamp backward), pass 2 scatters.
+// ------------------------------------------------------------------------------------------
+template <int JC>
+__global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const float *__restrict__ cam,
+                                                            const float *__restrict__ centers,
+                                                            const uint8_t *__restrict__ valid,
+                                                            const float *__restrict__ grad_cubes, ViewsMut ghm,
+                                                            Geom g)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * TILE + threadIdx.x;
+    if (n >= g.N || !valid[b]) return;
+    const int vx = n / g.YZ, rem = n - vx * g.YZ, vy = rem / g.Z, vz = rem - vy * g.Z;
+    const float x = linspace_at(g.Lx, g.X, vx) + centers[3 * b + 0];
+    const float y = linspace_at(g.Ly, g.Y, vy) + centers[3 * b + 1];
+    const float z = linspace_at(g.Lz, g.Z, vz) + centers[3 * b + 2];
+    const float W_in = (float)g.W_in, H_in = (float)g.H_in;
+    const size_t plane = (size_t)g.h * g.w;
+    const float *gc = grad_cubes + (size_t)b * g.J * g.N + n;
+    for (int j0 = 0; j0 < g.J; j0 += JC) {
+        float acc[JC];
+#pragma unroll
+        for (int k = 0; k < JC; ++k) acc[k] = 0.0f;
+        float cnt = 0.0f;
+        bool bad = false;
+        for (int c = 0; c < g.V; ++c) {
+            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            float ix, iy;
+            const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
+            cnt += bound ? 1.0f : 0.0f;
+            if (ix != ix || iy != iy) { bad = true; continue; }
+            if (!bound) continue;
+            const Bilin bl = bilin(ix, iy);
+            const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
+            const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
+            const float *base = hm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+#pragma unroll
+            for (int k = 0; k < JC; ++k) {
+                if (j0 + k < g.J) {
+                    const float *pl = base + (size_t)k * plane;
+                    const float t00 = (x0ok && y0ok) ? pl[0] : 0.0f;
+                    const float t10 = (x1ok && y0ok) ? pl[1] : 0.0f;
+                    const float t01 = (x0ok && y1ok) ? pl[g.w] : 0.0f;
+                    const float t11 = (x1ok && y1ok) ? pl[g.w + 1] : 0.0f;
+                    float v = t00 * bl.wnw;
+                    v = fmaf(t10, bl.wne, v);
+                    v = fmaf(t01, bl.wsw, v);
+                    v = fmaf(t11, bl.wse, v);
+                    acc[k] = acc[k] + v;
+                }
+            }
+        }
+        if (bad) continue;
+        const float den = cnt + 1e-6f;
+        float gs[JC];
+        bool anyg = false;
+#pragma unroll
+        for (int k = 0; k < JC; ++k) {
+            gs[k] = 0.0f;
+            if (j0 + k < g.J) {
+                const float pre = acc[k] / den;
+                if (pre >= 0.0f && pre <= 1.0f) {
+                    gs[k] = gc[(size_t)(j0 + k) * g.N] / den;
+                    anyg = anyg || (gs[k] != 0.0f);
+                }
+            }
+        }
+        if (!anyg) continue;
+        for (int c = 0; c < g.V; ++c) {
+            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            float ix, iy;
+            const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
+            if (!bound) continue;
+            const Bilin bl = bilin(ix, iy);
+            const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
+            const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
+            float *base = ghm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+#pragma unroll
+            for (int k = 0; k < JC; ++k) {
+                if (j0 + k < g.J && gs[k] != 0.0f) {
+                    float *pl = base + (size_t)k * plane;
+                    if (x0ok && y0ok) unsafeAtomicAdd(pl, gs[k] * bl.wnw);
+                    if (x1ok && y0ok) unsafeAtomicAdd(pl + 1, gs[k] * bl.wne);
+                    if (x0ok && y1ok) unsafeAtomicAdd(pl + g.w, gs[k] * bl.wsw);
+                    if (x1ok && y1ok) unsafeAtomicAdd(pl + g.w + 1, gs[k] * bl.wse);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------
+static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size,
+                     int W_in, int H_in)
+{
+    if (B <= 0 || V <= 0 || J <= 0 || h <= 0 || w <= 0 || X <= 0 || Y <= 0 || Z <= 0 || W_in <= 0 || H_in <= 0)
+        return SP3D_EINVAL;
+    if (V > SP3D_MAX_VIEWS) return SP3D_EINVAL;
+    if (!grid_size) return SP3D_ENULL;
+    const int64_t N = (int64_t)X * Y * Z;
+    if (N > (int64_t)0x7fffffff - TILE) return SP3D_ERANGE;
+    if ((int64_t)B * ((N + TILE - 1) / TILE) > (int64_t)0x7fffffff - 8) return SP3D_ERANGE;
+    if ((int64_t)h * w * 16 > (int64_t)0x7fffffff) return SP3D_ERANGE;
+    g.B = B; g.V = V; g.J = J; g.h = h; g.w = w; g.X = X; g.Y = Y; g.Z = Z;
+    g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
+    g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
+    return SP3D_OK;
+}
+
+static int load_views(Views &v, const float *const *hm_views, int V)
+{
+    if (!hm_views) return SP3D_ENULL;
+    for (int c = 0; c < SP3D_MAX_VIEWS; ++c) v.p[c] = nullptr;
+    for (int c = 0; c < V; ++c) {
+        if (!hm_views[c]) return SP3D_ENULL;
+        v.p[c] = hm_views[c];
+    }
+    return SP3D_OK;
+}
+
+static int launch_status()
+{
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+// variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable the XCD-aware tile map
+#define SP3D_DEFAULT_VARIANT 1
+
+template <int JP>
+static void launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
+                           float *grids, const Geom &g, int variant, hipStream_t s)
+{
+    const int tiles = (g.N + TILE - 1) / TILE;
+    const int total = tiles * g.B;
+    const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
+    const bool xcd = !(variant & 4);
+    dim3 grid(xcd ? ((total + 7) / 8) * 8 : total), block(TILE);
+#define SP3D_LAUNCH(XCD_, U_) \
+    hipLaunchKernelGGL((unproject_nhwc_kernel<JP, XCD_, U_>), grid, block, lds, s, v, cam, centers, valid, cubes, grids, g, tiles, total)
+    switch (variant & 3) {
+    case 0: if (xcd) SP3D_LAUNCH(true, 1); else SP3D_LAUNCH(false, 1); break;
+    case 2: if (xcd) SP3D_LAUNCH(true, 4); else SP3D_LAUNCH(false, 4); break;
+    default: if (xcd) SP3D_LAUNCH(true, 2); else SP3D_LAUNCH(false, 2); break;
+    }
+#undef SP3D_LAUNCH
+}
+
+static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *centers, const uint8_t *valid,
+                       float *cubes, float *grids, const Geom &g, int variant, hipStream_t s)
+{
+    if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
+    switch (Jp) {
+    case 4: launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
+    case 8: launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
+    case 12: launch_nhwc_jp<12>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
+    case 16: launch_nhwc_jp<16>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
+    default: return SP3D_EUNSUPPORTED;
+    }
+    return launch_status();
+}
+
+} // namespace sp3d
+
+using namespace sp3d;
+
+extern "C" int sp3d_abi_version(void) { return SP3D_ABI_VERSION; }
+
+extern "C" const char *sp3d_error_string(int code)
+{
+    switch (code) {
+    case SP3D_OK: return "ok";
+    case SP3D_EINVAL: return "invalid argument (dimension <= 0, too many views, unknown layout)";
+    case SP3D_ENULL: return "required pointer is NULL";
+    case SP3D_ERANGE: return "size overflows 32-bit kernel indexing";
+    case SP3D_EUNSUPPORTED: return "unsupported combination";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown sp3d error";
+    }
+}
+
+extern "C" int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V, int J, int Jp, int h,
+                                  int w, void *stream)
+{
+    if (B <= 0 || V <= 0 || J <= 0 || h <= 0 || w <= 0 || V > SP3D_MAX_VIEWS) return SP3D_EINVAL;
+    if (!packed) return SP3D_ENULL;
+    if (Jp < J || (Jp & 3)) return SP3D_EUNSUPPORTED;
+    Views v;
+    int rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    const int HW = h * w;
+    dim3 grid((HW + 255) / 256, B, V), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (Jp) {
+    case 4: hipLaunchKernelGGL(pack_nhwc_kernel<4>, grid, block, 0, s, v, packed, B, J, HW); break;
+    case 8: hipLaunchKernelGGL(pack_nhwc_kernel<8>, grid, block, 0, s, v, packed, B, J, HW); break;
+    case 16: hipLaunchKernelGGL(pack_nhwc_kernel<16>, grid, block, 0, s, v, packed, B, J, HW); break;
+    default: return SP3D_EUNSUPPORTED;
+    }
+    return launch_status();
+}
+
+extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                                  const float *centers, const uint8_t *valid, float *cubes, float *grids, int B,
+                                  int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
+                                  int H_in, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !cubes) return SP3D_ENULL;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = (g.N + TILE - 1) / TILE;
+    if (hm_layout == SP3D_LAYOUT_PLANAR) {
+        dim3 grid(tiles, B), block(TILE);
+        if (J == 1)
+            hipLaunchKernelGGL(unproject_planar_kernel<1>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
+        else if (J <= 4)
+            hipLaunchKernelGGL(unproject_planar_kernel<4>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
+        else
+            hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
+        return launch_status();
+    }
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT, s);
+    return SP3D_EINVAL;
+}
+
+extern "C" int sp3d_unproject_bwd(const float *const *hm_views, const float *cam, const float *centers,
+                                  const uint8_t *valid, const float *grad_cubes, float *const *grad_hm_views, int B,
+                                  int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
+                                  int H_in, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !grad_cubes || !grad_hm_views) return SP3D_ENULL;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    ViewsMut gv;
+    for (int c = 0; c < SP3D_MAX_VIEWS; ++c) gv.p[c] = nullptr;
+    for (int c = 0; c < V; ++c) {
+        if (!grad_hm_views[c]) return SP3D_ENULL;
+        gv.p[c] = grad_hm_views[c];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((g.N + TILE - 1) / TILE, B), block(TILE);
+    if (J == 1)
+        hipLaunchKernelGGL(unproject_bwd_kernel<1>, grid, block, 0, s, v, cam, centers, valid, grad_cubes, gv, g);
+    else if (J <= 4)
+        hipLaunchKernelGGL(unproject_bwd_kernel<4>, grid, block, 0, s, v, cam, centers, valid, grad_cubes, gv, g);
+    else
+        hipLaunchKernelGGL(unproject_bwd_kernel<16>, grid, block, 0, s, v, cam, centers, valid, grad_cubes, gv, g);
+    return launch_status();
+}
+
+// Not part of the drop-in ABI (declared in csrc/sp3d_tuning.h): same as sp3d_unproject_fwd for
+// the NHWC layout, with an explicit kernel variant, for A/B measurements (tools/ab_variants.py).
+extern "C" int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float *cam, const float *centers,
+                                          const uint8_t *valid, float *cubes, float *grids, int B, int V, int J,
+                                          int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
+                                          int H_in, int variant, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !cubes) return SP3D_ENULL;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant, (hipStream_t)stream);
+}

@@ -1,0 +1,72 @@
+"""Root-localisation net: unproject (coarse grid) -> V2V -> NMS/top-k proposals.
+
+Interface of /root/reference/lib/models/cuboid_proposal_net.py:86-122 (``CuboidProposalNet``)
+and :13-83 (``ProposalLayer``); checkpoint keys ``v2v_net.*`` are identical.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .project_layer import ProjectLayer
+from .proposal import nms_with_locations
+from .v2v_net import V2VNet
+
+
+class ProposalLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.grid_size = [float(v) for v in cfg.MULTI_PERSON.SPACE_SIZE]
+        self.cube_size = [int(v) for v in cfg.MULTI_PERSON.INITIAL_CUBE_SIZE]
+        self.grid_center = [float(v) for v in cfg.MULTI_PERSON.SPACE_CENTER]
+        self.num_cand = int(cfg.MULTI_PERSON.MAX_PEOPLE_NUM)
+        self.threshold = float(cfg.MULTI_PERSON.THRESHOLD)
+
+    @staticmethod
+    def match_to_gt(locs, gt_3d, num_person):
+        """index of the nearest GT root within 500 mm, else -1 (cuboid_proposal_net.py:25-40), batched."""
+        B, K, _ = locs.shape
+        P = gt_3d.shape[1]
+        d = torch.sqrt(((locs[:, :, None, :] - gt_3d[:, None, :, :]) ** 2).sum(-1))      # (B,K,P)
+        live = torch.arange(P, device=locs.device)[None, None, :] < num_person.to(locs.device).view(B, 1, 1)
+        d = torch.where(live, d, torch.full_like(d, float("inf")))
+        min_dist, min_gt = d.min(dim=-1)
+        out = min_gt.float()
+        out[min_dist > 500.0] = -1.0
+        return out
+
+    def forward(self, root_cubes, meta):
+        B = root_cubes.shape[0]
+        vals, _idx, locs = nms_with_locations(root_cubes, self.num_cand, self.grid_size, self.grid_center)
+        grid_centers = torch.zeros(B, self.num_cand, 5, device=root_cubes.device)
+        grid_centers[:, :, 0:3] = locs
+        grid_centers[:, :, 4] = vals
+        if self.training and ("roots_3d" in meta[0] and "num_person" in meta[0]):
+            gt = meta[0]["roots_3d"].float().to(root_cubes.device)
+            grid_centers[:, :, 3] = self.match_to_gt(locs, gt, meta[0]["num_person"])
+        else:
+            grid_centers[:, :, 3] = (vals > self.threshold).float() - 1.0
+        return grid_centers
+
+
+class CuboidProposalNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.grid_size = [float(v) for v in cfg.MULTI_PERSON.SPACE_SIZE]
+        self.cube_size = [int(v) for v in cfg.MULTI_PERSON.INITIAL_CUBE_SIZE]
+        self.grid_center = [float(v) for v in cfg.MULTI_PERSON.SPACE_CENTER]
+        self.rootnet_roothm = bool(cfg.NETWORK.ROOTNET_ROOTHM)
+        self.root_id = cfg.DATASET.ROOTIDX_PSEUDO
+        self.project_layer = ProjectLayer(cfg)
+        self.v2v_net = V2VNet(1 if self.rootnet_roothm else int(cfg.NETWORK.NUM_JOINTS), 1)
+        self.proposal_layer = ProposalLayer(cfg)
+
+    def forward(self, all_heatmaps, meta, flip_xcoords=None):
+        if self.rootnet_roothm:                                   # root-joint channel only (:103-108)
+            hms = [a[:, self.root_id:self.root_id + 1].contiguous() for a in all_heatmaps]
+        else:
+            hms = all_heatmaps
+        cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
+                                                flip_xcoords=flip_xcoords, want_grids=False)
+        root_cubes = self.v2v_net(cubes).squeeze(1)
+        return root_cubes, self.proposal_layer(root_cubes, meta)

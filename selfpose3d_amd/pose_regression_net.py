@@ -1,0 +1,50 @@
+"""Per-proposal pose net: unproject (fine grid around each proposal) -> V2V -> soft-argmax.
+
+Interface of /root/reference/lib/models/pose_regression_net.py:14-53; checkpoint keys
+``v2v_net.*`` identical.  The soft-argmax (softmax(beta x) . grid) is one HIP reduction
+kernel (sp3d_soft_argmax) in inference; under autograd it stays on torch ops.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .project_layer import ProjectLayer
+from .v2v_net import V2VNet
+
+
+class SoftArgmaxLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.beta = float(cfg.NETWORK.BETA)
+
+    def forward(self, x, grids):
+        if torch.is_grad_enabled() and x.requires_grad:
+            B, C = x.shape[:2]
+            p = F.softmax(self.beta * x.reshape(B, C, -1, 1), dim=2)
+            return (p * grids.unsqueeze(1)).sum(dim=2)
+        return _lib.soft_argmax(x, grids, self.beta)
+
+
+class PoseRegressionNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.grid_size = [float(v) for v in cfg.PICT_STRUCT.GRID_SIZE]
+        self.cube_size = [int(v) for v in cfg.PICT_STRUCT.CUBE_SIZE]
+        self.project_layer = ProjectLayer(cfg)
+        self.v2v_net = V2VNet(int(cfg.NETWORK.NUM_JOINTS), int(cfg.NETWORK.NUM_JOINTS))
+        self.soft_argmax_layer = SoftArgmaxLayer(cfg)
+
+    def forward(self, all_heatmaps, meta, grid_centers, flip_xcoords=None):
+        B, J = all_heatmaps[0].shape[:2]
+        device = all_heatmaps[0].device
+        pred = torch.zeros(B, J, 3, device=device)
+        cubes, grids = self.project_layer(all_heatmaps, meta, self.grid_size, grid_centers, self.cube_size,
+                                          flip_xcoords=flip_xcoords)
+        index = grid_centers[:, 3] >= 0
+        if bool(index.any()):
+            valid_cubes = self.v2v_net(cubes[index])
+            pred[index] = self.soft_argmax_layer(valid_cubes, grids[index])
+        return pred

@@ -1,0 +1,125 @@
+"""Drop-in replacement for the reference's ``models.project_layer.ProjectLayer``.
+
+Same constructor and call signature as /root/reference/lib/models/project_layer.py:15-106
+
+    ProjectLayer(cfg)
+    forward(heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None) -> (cubes, grids)
+
+but the batch x view Python loop of ~90 tiny kernels per (sample, view) is replaced by one
+host-side camera-table pack (cached while ``meta`` is unchanged) and one or two launches of
+the hand-written gfx950 kernels behind the C ABI in include/sp3d.h.  There is no CPU path:
+tensors must live on the GPU and libsp3d.so must be built, otherwise this raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .camera_pack import meta_cache_key, pack_cameras
+
+
+class _UnprojectFn(torch.autograd.Function):
+    """autograd seam: gradient flows to the heat-maps only."""
+
+    @staticmethod
+    def forward(ctx, layer, cam, centers, valid, grid_size, cube_size, want_grids, mode, *heatmaps):
+        B, J, h, w = heatmaps[0].shape
+        hms = [x.detach() for x in heatmaps]
+        hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
+        if mode == "nhwc":
+            packed = _lib.pack_heatmaps(hms, jp=layer.jp_for(J))
+            views = [packed[c] for c in range(len(hms))]
+            cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, packed.shape[-1], cam, centers, valid, B, J, h,
+                                              w, cube_size, grid_size, layer.img_size, want_grids)
+        else:
+            cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
+                                              grid_size, layer.img_size, want_grids)
+        ctx.layer = layer
+        ctx.geom = (tuple(grid_size), tuple(cube_size))
+        ctx.save_for_backward(cam, centers, valid, *hms)
+        if grids is None:
+            grids = torch.empty(0, device=cubes.device)
+        ctx.mark_non_differentiable(grids)
+        return cubes, grids
+
+    @staticmethod
+    def backward(ctx, grad_cubes, _grad_grids):
+        cam, centers, valid, *hms = ctx.saved_tensors
+        grid_size, cube_size = ctx.geom
+        grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size)
+        return (None,) * 8 + tuple(grads)
+
+
+class ProjectLayer(nn.Module):
+    """See module docstring.  ``mode``: "nhwc" (re-tile + fast kernel, J <= 16), "planar"
+    (direct kernel on the reference layout) or "auto"."""
+
+    def __init__(self, cfg, mode: str = "auto"):
+        super().__init__()
+        self.img_size = [int(v) for v in cfg.NETWORK.IMAGE_SIZE]        # project_layer.py:19
+        self.heatmap_size = [int(v) for v in cfg.NETWORK.HEATMAP_SIZE]  # project_layer.py:20
+        self.mode = mode
+        self._cam_key = None
+        self._cam_dev = None
+
+    @staticmethod
+    def jp_for(J: int) -> int:
+        return 4 if J <= 4 else (8 if J <= 8 else (12 if J <= 12 else 16))
+
+    # -- host side -----------------------------------------------------------------------
+    def camera_table(self, meta: Sequence[dict], batch: int, flip_xcoords, device) -> torch.Tensor:
+        key = (meta_cache_key(meta, flip_xcoords, self.img_size), batch, str(device))
+        if key != self._cam_key:
+            tab = pack_cameras(meta, batch, self.img_size, flip_xcoords)
+            self._cam_dev = torch.from_numpy(tab).to(device, non_blocking=False)
+            self._cam_key = key
+        return self._cam_dev
+
+    @staticmethod
+    def centers_valid(grid_center, batch: int, device):
+        """(centers (B,3) fp32, valid (B) uint8) following project_layer.py:54,58-61."""
+        if isinstance(grid_center, torch.Tensor):
+            gc = grid_center.to(device=device, dtype=torch.float32)
+            if gc.dim() == 1:
+                gc = gc[None]
+        else:
+            gc = torch.as_tensor(np.asarray(grid_center, dtype=np.float32), device=device)
+        rows, cols = gc.shape
+        if cols == 3:                       # `len(grid_center[0]) == 3`: always valid
+            valid = torch.ones(batch, dtype=torch.uint8, device=device)
+        else:
+            flag = gc[:, 3] >= 0
+            valid = (flag if rows == batch else flag[:1].expand(batch)).to(torch.uint8)
+        centers = gc[:, :3]
+        if rows == 1 and batch > 1:         # `len(grid_center) == 1`: shared centre
+            centers = centers.expand(batch, 3)
+        return centers.contiguous(), valid.contiguous()
+
+    # -- reference API -------------------------------------------------------------------
+    def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True):
+        device = heatmaps[0].device
+        if not heatmaps[0].is_cuda:
+            raise _lib.Sp3dError("ProjectLayer: heat-maps must be on the GPU (no CPU fallback)")
+        B, J, h, w = heatmaps[0].shape
+        if [w, h] != self.heatmap_size:
+            # the reference samples with cfg HEATMAP_SIZE (project_layer.py:50) whatever the tensor says
+            raise _lib.Sp3dError(f"heat-map tensor is {w}x{h} but cfg.NETWORK.HEATMAP_SIZE is {self.heatmap_size}")
+        cam = self.camera_table(meta, B, flip_xcoords, device)
+        centers, valid = self.centers_valid(grid_center, B, device)
+        if isinstance(cube_size, int):
+            cube_size = [cube_size] * 3
+        if isinstance(grid_size, (int, float)):
+            grid_size = [grid_size] * 3
+        mode = self.mode
+        if mode == "auto":
+            mode = "nhwc" if J <= 16 else "planar"
+        cubes, grids = _UnprojectFn.apply(self, cam, centers, valid, [float(v) for v in grid_size],
+                                          [int(v) for v in cube_size], bool(want_grids), mode, *heatmaps)
+        return cubes, (grids if want_grids else None)
+
+    def forward(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None):
+        return self.get_voxel(heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=flip_xcoords)

@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+reference goldens.  Run on the MI355X box: python -m pytest tests -m gpu
+
+Tolerances: north_star asks <=1e-4 on voxel values and bit-exact integer indices.  The kernels
+follow the oracle's fp32 operation order exactly, so the assertions below are much tighter
+(VOX_TOL); grids and NMS indices must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_io as gio
+
+pytestmark = pytest.mark.gpu
+
+VOX_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _oracle_fwd(case):
+    from oracle import oracle
+    return oracle.unproject_fwd([h.numpy() for h in case.hms], case.cam, case.centers, case.valid, case.grid_size,
+                                case.cube, case.img)
+
+
+def _hip_fwd(case, dev, layout, want_grids=True, variant=None):
+    from selfpose3d_amd import _lib
+    hms = [h.to(dev) for h in case.hms]
+    cam = torch.from_numpy(case.cam).to(dev)
+    centers = torch.from_numpy(case.centers).to(dev)
+    valid = torch.from_numpy(case.valid).to(dev)
+    w, h = case.hm
+    if layout == "planar":
+        return _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, case.B, case.J, h, w, case.cube,
+                                  case.grid_size, case.img, want_grids)
+    jp = 4 if case.J <= 4 else (8 if case.J <= 8 else (12 if case.J <= 12 else 16))
+    packed = _lib.pack_heatmaps(hms, jp=jp)
+    views = [packed[c] for c in range(case.V)]
+    return _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, case.B, case.J, h, w, case.cube,
+                              case.grid_size, case.img, want_grids, variant=variant)
+
+
+def test_pack_heatmaps(dev):
+    from selfpose3d_amd import _lib
+    rng = np.random.default_rng(0)
+    for (B, V, J, h, w, jp) in [(2, 3, 15, 18, 24, 16), (1, 1, 1, 7, 5, 4), (3, 5, 7, 33, 65, 8), (1, 2, 12, 16, 16, 12)]:
+        hms = [torch.from_numpy(rng.standard_normal((B, J, h, w)).astype(np.float32)).to(dev) for _ in range(V)]
+        packed = _lib.pack_heatmaps(hms, jp=jp).cpu()
+        assert packed.shape == (V, B, h, w, jp)
+        for c in range(V):
+            exp = hms[c].cpu().permute(0, 2, 3, 1)
+            assert torch.equal(packed[c, ..., :J], exp)
+            assert torch.count_nonzero(packed[c, ..., J:]) == 0
+
+
+@pytest.mark.parametrize("layout", ["planar", "nhwc"])
+@pytest.mark.parametrize("name", gio.SMALL_CASES + gio.FULL_CASES)
+def test_unproject_fwd_vs_oracle_and_golden(dev, name, layout):
+    case = gio.Case(name)
+    cubes, grids = _hip_fwd(case, dev, layout)
+    cubes = cubes.cpu().numpy()
+    grids = grids.cpu().numpy()
+    ref_c, ref_g = _oracle_fwd(case)
+    assert np.array_equal(grids, ref_g), "grids must be bit-exact vs oracle"
+    d = np.abs(cubes - ref_c)
+    assert d.max() <= VOX_TOL, (name, layout, float(d.max()))
+    # committed reference goldens (sub-sampled for the full-size cases) + whole-volume checksums
+    exp_c, exp_g, idx = case.expected()
+    got_c = cubes.reshape(case.B, case.J, case.N)
+    got_g = grids
+    if idx is not None:
+        got_c, got_g = got_c[:, :, idx], grids[:, idx]
+    assert np.array_equal(got_g, exp_g)
+    assert np.abs(got_c - exp_c).max() <= VOX_TOL
+    assert abs(cubes.astype(np.float64).sum() - float(case.g["cubes_sum"])) <= 1e-7 * cubes.size
+    print(f"{name}/{layout}: max|d| vs oracle {d.max():.3e}, bit-equal {float((cubes == ref_c).mean()):.6f}")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
+def test_nhwc_variants_bit_identical(dev, variant):
+    case = gio.Case("unproj_coarse_full_96x72")
+    base, _ = _hip_fwd(case, dev, "planar")
+    got, _ = _hip_fwd(case, dev, "nhwc", variant=variant)
+    assert torch.equal(base, got)
+
+
+def test_no_grids_and_invalid_rows(dev):
+    case = gio.Case("unproj_fine_small")          # row 1 is invalid (flag < 0)
+    for layout in ("planar", "nhwc"):
+        cubes, grids = _hip_fwd(case, dev, layout, want_grids=False)
+        assert grids is None
+        assert torch.count_nonzero(cubes[1]) == 0
+        cubes2, grids2 = _hip_fwd(case, dev, layout, want_grids=True)
+        assert torch.equal(cubes, cubes2)
+        assert torch.count_nonzero(grids2[1]) == 0
+
+
+def test_properties_full_size(dev):
+    """size-independent properties at BASELINE sizes (B=4, 5 views, 240x128, 80x80x20)."""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.camera_pack import pack_cameras
+    B, V, J, h, w = 4, 5, 15, 128, 240
+    img = (960, 512)
+    meta = syn.make_meta(B, V, img)
+    cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
+    centers = torch.tensor([syn.SPACE_CENTER] * B, dtype=torch.float32, device=dev)
+    valid = torch.ones(B, dtype=torch.uint8, device=dev)
+    cube, gs = syn.INITIAL_CUBE_SIZE, syn.SPACE_SIZE
+
+    def run(hms, layout="nhwc"):
+        if layout == "planar":
+            return _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)[0]
+        p = _lib.pack_heatmaps(hms, jp=16)
+        return _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
+                                  cube, gs, img, False)[0]
+
+    a = [0.5 * x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=100)]
+    b = [0.5 * x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=101)]
+    ua, ub = run(a), run(b)
+    # 1. the two independent kernels agree bit for bit
+    assert torch.equal(ua, run(a, "planar"))
+    # 2. linearity while the clamp is inactive (values < 1): u(a+b) == u(a)+u(b) up to fp32 rounding
+    uab = run([x + y for x, y in zip(a, b)])
+    assert float((uab - (ua + ub)).abs().max()) <= 5e-6
+    # 3. zero in, zero out; constant c in => c wherever all taps are inside (never above c)
+    z = [torch.zeros_like(x) for x in a]
+    assert torch.count_nonzero(run(z)) == 0
+    c = [torch.full_like(x, 0.25) for x in a]
+    uc = run(c)
+    assert float(uc.max()) <= 0.25 + 1e-6
+    assert float((uc - 0.25).abs().median()) <= 1e-6
+    # 4. channels are independent: channel j of the J=15 result == the J=1 run on channel j alone
+    j = 7
+    a1 = [x[:, j:j + 1].contiguous() for x in a]
+    p1 = _lib.pack_heatmaps(a1, jp=4)
+    u1 = _lib.unproject_fwd([p1[c] for c in range(V)], _lib.LAYOUT_NHWC, 4, cam, centers, valid, B, 1, h, w, cube, gs,
+                            img, False)[0]
+    assert torch.equal(u1[:, 0], ua[:, j])
+    # 5. samples are independent: permuting the batch permutes the output
+    perm = [2, 0, 3, 1]
+    up = run([x[perm].contiguous() for x in a])
+    assert torch.equal(up, ua[perm])
+    # 6. range
+    assert float(ua.min()) >= 0.0 and float(ua.max()) <= 1.0
+
+
+@pytest.mark.parametrize("name", ["unproj_grad_small", "unproj_grad_fine_aug"])
+def test_unproject_bwd(dev, name):
+    from oracle import oracle
+    from selfpose3d_amd import _lib
+    case = gio.Case(name)
+    g = case.g
+    wgt = np.random.default_rng(int(g["grad_seed"])).standard_normal((case.B, case.J, *case.cube)).astype(np.float32)
+    hms = [h.to(dev) for h in case.hms]
+    grads = _lib.unproject_bwd(hms, torch.from_numpy(case.cam).to(dev), torch.from_numpy(case.centers).to(dev),
+                               torch.from_numpy(case.valid).to(dev), torch.from_numpy(wgt).to(dev), case.cube,
+                               case.grid_size, case.img)
+    ref = oracle.unproject_bwd([h.numpy() for h in case.hms], case.cam, case.centers, case.valid, wgt, case.grid_size,
+                               case.cube, case.img)
+    gold = g["grad_hm"]
+    for c in range(case.V):
+        got = grads[c].cpu().numpy()
+        scale = max(1.0, float(np.abs(ref[c]).max()))
+        assert np.abs(got - ref[c]).max() <= 2e-5 * scale
+        assert np.abs(got - gold[c]).max() <= 2e-5 * scale
+
+
+def test_autograd_through_project_layer(dev):
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    case = gio.Case("unproj_grad_fine_aug")
+    g = case.g
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+    layer = ProjectLayer(cfg)
+    hms = [h.to(dev).requires_grad_(True) for h in case.hms]
+    cubes, grids = layer(hms, case.meta, case.grid_size, case.grid_center.to(dev), case.cube,
+                         flip_xcoords=case.flip)
+    assert not grids.requires_grad
+    wgt = torch.from_numpy(np.random.default_rng(int(g["grad_seed"])).standard_normal(
+        tuple(cubes.shape)).astype(np.float32)).to(dev)
+    (cubes * wgt).sum().backward()
+    exp_c, exp_g, _ = case.expected()
+    assert np.abs(cubes.detach().cpu().numpy().reshape(exp_c.shape) - exp_c).max() <= VOX_TOL
+    for c in range(case.V):
+        scale = max(1.0, float(np.abs(g["grad_hm"][c]).max()))
+        assert np.abs(hms[c].grad.cpu().numpy() - g["grad_hm"][c]).max() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("name", ["unproj_coarse_small", "unproj_coarse_aug", "unproj_fine_small"])
+@pytest.mark.parametrize("mode", ["planar", "nhwc"])
+def test_project_layer_module_reference_api(dev, name, mode):
+    """through the reference's own call signature: list of heat-maps + collated meta dicts"""
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    case = gio.Case(name)
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+    layer = ProjectLayer(cfg, mode=mode)
+    gc = case.grid_center if isinstance(case.grid_center, list) else case.grid_center.to(dev)
+    cubes, grids = layer([h.to(dev) for h in case.hms], case.meta, case.grid_size, gc, case.cube,
+                         flip_xcoords=case.flip)
+    exp_c, exp_g, _ = case.expected()
+    assert cubes.shape == (case.B, case.J, *case.cube) and grids.shape == (case.B, case.N, 3)
+    assert np.array_equal(grids.cpu().numpy(), exp_g)
+    assert np.abs(cubes.cpu().numpy().reshape(exp_c.shape) - exp_c).max() <= VOX_TOL
+
+
+def test_nms_topk(dev):
+    from oracle import oracle
+    from selfpose3d_amd import _lib, synthetic as syn
+    g = gio.load("nms")
+    rnd = np.random.default_rng(int(g["rnd_seed"])).random(tuple(g["rnd_shape"]), dtype=np.float32)
+    vals, idx, locs = _lib.nms_topk(torch.from_numpy(rnd).to(dev), 10, [8000.0, 8000.0, 2000.0], [0.0, -500.0, 800.0])
+    assert np.array_equal(vals.cpu().numpy(), g["rnd_vals"])
+    assert np.array_equal(idx.cpu().numpy(), g["rnd_idx"])
+    # people case at full coarse size, against the oracle and the reference golden
+    case = gio.Case("unproj_people_coarse")
+    cubes, _ = _hip_fwd(case, dev, "nhwc", want_grids=False)
+    root = cubes[:, 2].contiguous()
+    vals, idx, locs = _lib.nms_topk(root, 10, syn.SPACE_SIZE, syn.SPACE_CENTER)
+    rv, ri = oracle.nms_topk(root.cpu().numpy(), 10)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)
+    pos = g["people_vals"] > 0
+    assert np.array_equal(idx.cpu().numpy()[pos], g["people_idx"][pos])
+    assert np.abs(vals.cpu().numpy() - g["people_vals"]).max() <= VOX_TOL
+    # index -> mm (cuboid_proposal_net.py:42-52) in fp32
+    cs = torch.tensor(case.cube, dtype=torch.float32)
+    gs = torch.tensor(syn.SPACE_SIZE)
+    gcen = torch.tensor(syn.SPACE_CENTER)
+    exp_loc = idx.cpu().float() / (cs - 1) * gs + gcen - gs / 2.0
+    assert torch.equal(locs.cpu(), exp_loc)
+    # ties: constant volume -> every voxel is a local max, lowest flat indices win in order
+    flat = torch.full((1, 6, 5, 4), 0.5, device=dev)
+    vals, idx, _ = _lib.nms_topk(flat, 7)
+    exp = torch.tensor([[n // 20, (n % 20) // 4, n % 4] for n in range(7)])
+    assert torch.equal(idx.cpu()[0], exp) and torch.all(vals == 0.5)
+    # empty-ish: all zeros and k larger than the number of positive peaks
+    zero = torch.zeros((2, 8, 8, 4), device=dev)
+    vals, idx, _ = _lib.nms_topk(zero, 10)
+    assert torch.count_nonzero(vals) == 0
+
+
+def test_soft_argmax(dev):
+    from oracle import oracle
+    from selfpose3d_amd import _lib
+    rng = np.random.default_rng(5)
+    for (Bv, J, n) in [(2, 3, 16), (1, 15, 64)]:
+        x = rng.random((Bv, J, n, n, n), dtype=np.float32) * 0.3
+        for b in range(Bv):
+            for j in range(J):
+                x[b, j, rng.integers(n), rng.integers(n), rng.integers(n)] = 0.9
+        grids = (rng.random((Bv, n ** 3, 3), dtype=np.float32) - 0.5) * 2000.0
+        out = _lib.soft_argmax(torch.from_numpy(x).to(dev), torch.from_numpy(grids).to(dev), 100.0).cpu().numpy()
+        ref = oracle.soft_argmax(x, grids, 100.0)
+        assert np.abs(out - ref).max() <= 2e-2, float(np.abs(out - ref).max())   # mm, on +-1000 mm coordinates
+
+
+def test_rootnet_posenet_vs_reference_golden(dev):
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    from selfpose3d_amd.pose_regression_net import PoseRegressionNet
+    g = gio.load("rootnet_posenet")
+    B, V, J = int(g["B"]), int(g["V"]), int(g["J"])
+    img, hm = [int(v) for v in g["img"]], [int(v) for v in g["hm"]]
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=img, NETWORK__HEATMAP_SIZE=hm, NETWORK__NUM_JOINTS=J,
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[int(v) for v in g["cube"]],
+                      PICT_STRUCT__CUBE_SIZE=[int(v) for v in g["fine_cube"]],
+                      MULTI_PERSON__THRESHOLD=float(g["threshold"]))
+    meta = syn.make_meta(B, V, img)
+    hms, _ = syn.people_heatmaps(B, V, J, hm[1], hm[0], img, seed=int(g["hm_seed"]))
+    hms = [h.to(dev) for h in hms]
+    rootnet = CuboidProposalNet(cfg)
+    assert sorted(rootnet.state_dict().keys()) == list(g["root_keys"])
+    syn.fill_parameters_deterministic(rootnet, seed=int(g["root_seed"]), scale=float(g["param_scale"]))
+    rootnet.eval().to(dev)
+    posenet = PoseRegressionNet(cfg)
+    assert sorted(posenet.state_dict().keys()) == list(g["pose_keys"])
+    syn.fill_parameters_deterministic(posenet, seed=int(g["pose_seed"]), scale=float(g["param_scale"]))
+    posenet.eval().to(dev)
+    prev = torch.backends.cudnn.allow_tf32
+    with torch.no_grad():
+        root_cubes, grid_centers = rootnet(hms, meta)
+        assert float((root_cubes.cpu() - torch.from_numpy(g["root_cubes"])).abs().max()) <= 2e-4
+        gc_ref = torch.from_numpy(g["grid_centers"])
+        # compare proposal slots whose score is separated from its neighbours (MIOpen vs CPU conv rounding)
+        sc = gc_ref[:, :, 4]
+        for b in range(B):
+            for k in range(sc.shape[1]):
+                gap = min(abs(float(sc[b, k] - sc[b, k - 1])) if k > 0 else 1.0,
+                          abs(float(sc[b, k] - sc[b, k + 1])) if k + 1 < sc.shape[1] else 1.0)
+                if gap > 1e-3:
+                    assert torch.equal(grid_centers[b, k, :4].cpu(), gc_ref[b, k, :4]), (b, k)
+                    assert abs(float(grid_centers[b, k, 4].cpu() - gc_ref[b, k, 4])) <= 2e-4
+        for n in range(g["preds"].shape[0]):
+            pred = posenet(hms, meta, gc_ref[:, n].to(dev))
+            assert float((pred.cpu() - torch.from_numpy(g["preds"][n])).abs().max()) <= 0.5   # mm
+    torch.backends.cudnn.allow_tf32 = prev

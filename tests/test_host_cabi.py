@@ -1,0 +1,143 @@
+"""CPU-side tests: the C-ABI library loads and exports everything include/sp3d.h declares,
+argument validation happens before any GPU work, and the host logic (camera table, grid
+centres, config) behaves like the reference's.  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from selfpose3d_amd import _lib, build as sbuild, synthetic as syn
+from selfpose3d_amd.camera_pack import (CAM_A, CAM_FLIP, CAM_H0, CAM_STRIDE, CAM_W0, meta_cache_key, pack_cameras)
+from selfpose3d_amd.config import default_config, load_config
+from selfpose3d_amd.project_layer import ProjectLayer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    sbuild.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "sp3d.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(sp3d_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 8
+    assert sorted(_lib.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sp3d_abi_version() == 1
+    # header constants match the python binding
+    for macro, val in (("SP3D_CAM_STRIDE", CAM_STRIDE), ("SP3D_CAM_A", CAM_A), ("SP3D_CAM_W0", CAM_W0),
+                       ("SP3D_CAM_H0", CAM_H0), ("SP3D_CAM_FLIP", CAM_FLIP), ("SP3D_MAX_VIEWS", _lib.MAX_VIEWS),
+                       ("SP3D_MAX_TOPK", _lib.MAX_TOPK)):
+        m = re.search(r"#define\s+%s\s+(\d+)" % macro, hdr)
+        assert m and int(m.group(1)) == val, macro
+
+
+def test_argument_validation_before_any_launch(lib):
+    gs = (C.c_float * 3)(8000, 8000, 2000)
+    views = (C.c_void_p * 2)(0x1000, 0x1000)      # never dereferenced: validation fails first
+    dummy = C.c_void_p(0x1000)
+    f = lib.sp3d_unproject_fwd
+    # dimension <= 0
+    assert f(views, 0, 0, dummy, dummy, dummy, dummy, None, 0, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -1
+    # too many views
+    assert f(views, 0, 0, dummy, dummy, dummy, dummy, None, 1, 17, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -1
+    # voxel count overflow
+    assert f(views, 0, 0, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 2048, 2048, 2048, gs, 96, 72, None) == -3
+    # null pointers
+    assert f(views, 0, 0, None, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -2
+    assert f(None, 0, 0, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -2
+    assert f(views, 0, 0, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, None, 96, 72, None) == -2
+    # NHWC with a channel stride that is not a multiple of 4 / smaller than J / unknown layout
+    assert f(views, 1, 15, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -4
+    assert f(views, 1, 8, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -4
+    assert f(views, 7, 16, dummy, dummy, dummy, dummy, None, 1, 2, 15, 8, 8, 4, 4, 4, gs, 96, 72, None) == -1
+    assert lib.sp3d_pack_heatmaps(views, None, 1, 2, 15, 16, 8, 8, None) == -2
+    assert lib.sp3d_pack_heatmaps(views, dummy, 1, 2, 15, 15, 8, 8, None) == -4
+    assert lib.sp3d_nms_topk(dummy, 1, 4, 4, 4, 33, None, None, dummy, dummy, None, dummy, None) == -1
+    assert lib.sp3d_nms_topk(None, 1, 4, 4, 4, 10, None, None, dummy, dummy, None, dummy, None) == -2
+    assert lib.sp3d_nms_topk_workspace_bytes(4, 80, 80, 20, 10) == 4 * 63 * 10 * 8
+    assert lib.sp3d_soft_argmax(dummy, dummy, dummy, 0, 15, 64, C.c_float(100.0), None) == -1
+    assert b"NULL" in lib.sp3d_error_string(-2)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Sp3dError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_project_layer_refuses_cpu_tensors():
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[96, 72], NETWORK__HEATMAP_SIZE=[24, 18])
+    layer = ProjectLayer(cfg)
+    meta = syn.make_meta(1, 2, (96, 72))
+    hms = syn.random_heatmaps(1, 2, 3, 18, 24)
+    with pytest.raises(_lib.Sp3dError, match="GPU"):
+        layer(hms, meta, syn.SPACE_SIZE, [list(syn.SPACE_CENTER)], [4, 4, 4])
+
+
+def test_camera_table_fields_and_cache_key():
+    B, V, img = 3, 4, (192, 144)
+    flip = torch.tensor([False, True, True])
+    meta = syn.make_meta(B, V, img, rotations=[0.0, 30.0, -30.0], scale_mults=[1.0, 1.3, 0.8], ssv_style=True)
+    tab = pack_cameras(meta, B, img, flip)
+    assert tab.shape == (B, V, CAM_STRIDE) and tab.dtype == np.float32
+    assert np.all(tab[:, :, CAM_W0] == 1920.0) and np.all(tab[:, :, CAM_H0] == 1080.0)
+    assert np.array_equal(tab[:, 0, CAM_FLIP], np.array([0.0, 1.0, 1.0], np.float32))
+    R = tab[:, :, 0:9].reshape(B, V, 3, 3)
+    assert np.allclose(np.einsum("bvij,bvkj->bvik", R, R), np.eye(3), atol=1e-6)
+    # rot = 0 closed form: a = W_in / (200*scale_w), t = [W_in/2, H_in/2] - a*center
+    A = tab[0, 0, CAM_A:CAM_A + 6].reshape(2, 3)
+    a = img[0] / (200.0 * float(meta[0]["scale"][0, 0]))
+    assert np.allclose(A, [[a, 0, img[0] / 2 - a * 960.0], [0, a, img[1] / 2 - a * 540.0]], atol=1e-5)
+    k1 = meta_cache_key(meta, flip, img)
+    assert k1 == meta_cache_key(meta, flip, img)
+    meta[0]["scale"].mul_(1.0)          # in-place edit bumps the tensor version -> new key
+    assert k1 != meta_cache_key(meta, flip, img)
+
+
+def test_centers_valid_follow_reference_rules():
+    dev = torch.device("cpu")
+    c, v = ProjectLayer.centers_valid([[0.0, -500.0, 800.0]], 3, dev)           # shared list centre
+    assert c.shape == (3, 3) and torch.all(v == 1) and torch.all(c[:, 1] == -500.0)
+    gc = torch.tensor([[1.0, 2.0, 3.0, 0.0, 0.9], [4.0, 5.0, 6.0, -1.0, 0.1]])
+    c, v = ProjectLayer.centers_valid(gc, 2, dev)                                # per-sample (B,5)
+    assert torch.equal(c, gc[:, :3]) and v.tolist() == [1, 0]
+    c, v = ProjectLayer.centers_valid(gc[:1], 1, dev)
+    assert v.tolist() == [1]
+
+
+def test_config_reads_reference_yaml_shape(tmp_path):
+    y = tmp_path / "c.yaml"
+    y.write_text("NETWORK:\n  IMAGE_SIZE: [384, 288]\n  HEATMAP_SIZE: [96, 72]\n  SOME_NEW_KEY: 3\n"
+                 "MULTI_PERSON:\n  THRESHOLD: 0.1\n")
+    cfg = load_config(str(y))
+    assert cfg.NETWORK.IMAGE_SIZE == [384, 288] and cfg.MULTI_PERSON.THRESHOLD == 0.1
+    assert cfg.NETWORK.SOME_NEW_KEY == 3 and cfg.PICT_STRUCT.CUBE_SIZE == [64, 64, 64]
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("NO_SUCH_SECTION:\n  A: 1\n")
+    with pytest.raises(ValueError):
+        load_config(str(bad))
+    assert default_config().NETWORK.BETA == 100.0
+
+
+def test_v2v_matches_reference_golden_on_cpu():
+    from selfpose3d_amd.v2v_net import V2VNet
+    from tests import golden_io as gio
+    g = gio.load("v2v")
+    m = V2VNet(int(g["in_shape"][1]), 1)
+    assert sorted(m.state_dict().keys()) == list(g["keys"])
+    syn.fill_parameters_deterministic(m, seed=int(g["param_seed"]), scale=float(g["param_scale"]))
+    m.eval()
+    x = torch.from_numpy(np.random.default_rng(int(g["in_seed"])).random(tuple(g["in_shape"]), dtype=np.float32))
+    with torch.no_grad():
+        y = m(x)
+    assert float((y - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
