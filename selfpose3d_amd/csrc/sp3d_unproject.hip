@@ -490,6 +490,7 @@ extern "C" int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, i
     switch (Jp) {
     case 4: hipLaunchKernelGGL(pack_nhwc_kernel<4>, grid, block, 0, s, v, packed, B, J, HW); break;
     case 8: hipLaunchKernelGGL(pack_nhwc_kernel<8>, grid, block, 0, s, v, packed, B, J, HW); break;
+    case 12: hipLaunchKernelGGL(pack_nhwc_kernel<12>, grid, block, 0, s, v, packed, B, J, HW); break;
     case 16: hipLaunchKernelGGL(pack_nhwc_kernel<16>, grid, block, 0, s, v, packed, B, J, HW); break;
     default: return SP3D_EUNSUPPORTED;
     }
