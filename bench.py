@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (configs[1]: 4)")
     ap.add_argument("--roofline-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-reps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-reps", type=int, default=6)
     ap.add_argument("--cold", action="store_true", help="also time the kernel rotating >256 MiB of inputs (MALL-cold)")
     return ap.parse_args()
 
@@ -107,7 +107,7 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
     out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "sp3d::unproject_nhwc_kernel<16,true,2>", "kernel_us": round(t_nhwc * 1e3, 2),
+        "kernel": "sp3d::unproject_pipe_kernel<16,true,1>", "kernel_us": round(t_nhwc * 1e3, 2),
         "algorithmic_bytes": int(alg_bytes),
         "other_kernels_us": {"pack_nhwc_kernel<16>": round(t_pack * 1e3, 2),
                              "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},

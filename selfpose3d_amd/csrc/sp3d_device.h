@@ -27,6 +27,9 @@ struct Geom {
     int YZ;         // Y*Z
     int W_in, H_in; // network input size (cfg.NETWORK.IMAGE_SIZE)
     float Lx, Ly, Lz;
+    float rW_in, rH_in, rw1, rh1; // correctly rounded 1/W_in, 1/H_in, 1/(w-1), 1/(h-1)
+    float stepx, stepy, stepz;    // fp32 (end-start)/(n-1) of torch.linspace, computed on the host (same IEEE ops)
+    uint32_t magicYZ, magicZ;     // floor(2^32/d)+1 for d = Y*Z, Z (exact n/d with one fix-up, see udiv_magic)
 };
 
 // torch.linspace(-L/2, L/2, n)[i] in fp32 (project_layer.py:28-30; ATen CPU kernel form)
@@ -37,6 +40,26 @@ __device__ __forceinline__ float linspace_at(float L, int n, int i)
     const float step = (end - start) / (float)(n - 1);
     return (i < n / 2) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(n - 1 - i), end);
 }
+
+// linspace with the step precomputed on the host (bit-identical to linspace_at)
+__device__ __forceinline__ float linspace_step(float L, float step, int n, int i)
+{
+    const float start = -(L / 2.0f), end = L / 2.0f;
+    if (n == 1) return start;
+    return (i < n / 2) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(n - 1 - i), end);
+}
+
+// exact n / d for a uniform divisor d with magic = floor(2^32/d)+1: umulhi over-estimates by at most 1
+__device__ __forceinline__ void udiv_magic(uint32_t n, uint32_t d, uint32_t magic, int &q, int &r)
+{
+    uint32_t qq = d == 1 ? n : __umulhi(n, magic);
+    int rr = (int)(n - qq * d);
+    if (rr < 0) { qq -= 1; rr += (int)d; }
+    q = (int)qq; r = rr;
+}
+
+// clamp for values already known not to be NaN-relevant: one v_med3_f32 (NaN -> lo)
+__device__ __forceinline__ float clamp_fast(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
 __device__ __forceinline__ float clamp_nan(float v, float lo, float hi)
 {
@@ -85,6 +108,82 @@ __device__ __forceinline__ bool sample_pos(const float *__restrict__ cm, float x
     return bound;
 }
 
+// x / c for a wave-uniform constant c with rc = RN(1/c): one Newton correction on the residual
+// gives the correctly rounded quotient (verified exhaustively-by-sampling against IEEE division
+// for every constant used, tests/test_host_cabi.py::test_const_division_is_exact); 3 VALU ops
+// instead of the ~10 of the IEEE expansion.  x must be finite (it is: px,py are clamped).
+__device__ __forceinline__ float div_const(float x, float c, float rc)
+{
+    const float q = x * rc;
+    const float r = fmaf(-q, c, x);
+    return fmaf(r, rc, q);
+}
+
+// (x0/d, x1/d) with one shared reciprocal: the IEEE f32 division expansion (rcp, one Newton step on
+// the reciprocal, quotient, two residual corrections) minus its range scaling, which is the
+// identity for |d| in [2^-96, 2^96] and finite non-overflowing quotients.  d = depth + 1e-5 (mm):
+// only d == 0 or non-finite operands leave that range, and those take the plain IEEE path.
+__device__ __forceinline__ void div_pair(float x0, float x1, float d, float &q0, float &q1)
+{
+    const float ad = __builtin_fabsf(d);
+    if (__builtin_expect(!(ad >= 1e-20f && ad <= 1e20f), 0)) { q0 = x0 / d; q1 = x1 / d; return; }
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r, 1.0f);
+    r = fmaf(e, r, r);
+    float a = x0 * r, b = x1 * r;
+    a = fmaf(fmaf(-d, a, x0), r, a);
+    b = fmaf(fmaf(-d, b, x1), r, b);
+    q0 = fmaf(fmaf(-d, a, x0), r, a);
+    q1 = fmaf(fmaf(-d, b, x1), r, b);
+}
+
+// sample_pos with (a) the four divisions by image-size constants done by div_const and (b) NaN
+// tracked as a flag: a NaN can only be born before the first clamp (everything after it is a
+// bounded affine map of clamped values), so `isnan` = NaN(px)|NaN(py) and the clamps become
+// single v_med3_f32.  Same bits as sample_pos for ix, iy whenever isnan is false; when it is
+// true the caller zeroes the voxel exactly as a NaN sample position does in the reference.
+__device__ __forceinline__ bool sample_pos_fast(const float *__restrict__ cm, float x, float y, float z, const Geom &g,
+                                                float &ix, float &iy, bool &isnan)
+{
+    const float dx = x - cm[SP3D_CAM_T + 0], dy = y - cm[SP3D_CAM_T + 1], dz = z - cm[SP3D_CAM_T + 2];
+    const float xc = fmaf(cm[2], dz, fmaf(cm[1], dy, cm[0] * dx));
+    const float yc = fmaf(cm[5], dz, fmaf(cm[4], dy, cm[3] * dx));
+    const float zc = fmaf(cm[8], dz, fmaf(cm[7], dy, cm[6] * dx));
+    const float den = zc + 1e-5f;
+    float y0, y1;
+    div_pair(xc, yc, den, y0, y1);
+    float r2 = y0 * y0 + y1 * y1;
+    r2 = fminf(r2, 1e10f);        // NaN r2 -> 1e10, harmless: y0|y1 NaN already makes px,py NaN
+    const float r4 = r2 * r2, r6 = r4 * r2;
+    const float radial = 1.0f + ((cm[SP3D_CAM_K] * r2 + cm[SP3D_CAM_K + 1] * r4) + cm[SP3D_CAM_K + 2] * r6);
+    const float tan = cm[SP3D_CAM_P] * y1 + cm[SP3D_CAM_P + 1] * y0;
+    const float corr = radial + 2.0f * tan;
+    const float u0 = y0 * corr + cm[SP3D_CAM_P + 1] * r2;
+    const float u1 = y1 * corr + cm[SP3D_CAM_P] * r2;
+    float px = cm[SP3D_CAM_F] * u0 + cm[SP3D_CAM_C];
+    float py = cm[SP3D_CAM_F + 1] * u1 + cm[SP3D_CAM_C + 1];
+    const float W0 = cm[SP3D_CAM_W0], H0 = cm[SP3D_CAM_H0];
+    const bool bound = (px >= 0.0f) && (py >= 0.0f) && (px < W0) && (py < H0);
+    isnan = (px != px) || (py != py);
+    const float mx = W0 > H0 ? W0 : H0;
+    px = clamp_fast(px, -1.0f, mx);
+    py = clamp_fast(py, -1.0f, mx);
+    float qx = fmaf(cm[SP3D_CAM_A + 2], 1.0f, fmaf(cm[SP3D_CAM_A + 1], py, cm[SP3D_CAM_A + 0] * px));
+    const float qy = fmaf(cm[SP3D_CAM_A + 5], 1.0f, fmaf(cm[SP3D_CAM_A + 4], py, cm[SP3D_CAM_A + 3] * px));
+    const float W_in = (float)g.W_in, H_in = (float)g.H_in;
+    if (cm[SP3D_CAM_FLIP] != 0.0f) qx = W_in - qx;
+    const float ux = div_const(qx * (float)g.w, W_in, g.rW_in);
+    const float uy = div_const(qy * (float)g.h, H_in, g.rH_in);
+    float gx = div_const(ux, (float)(g.w - 1), g.rw1) * 2.0f - 1.0f;
+    float gy = div_const(uy, (float)(g.h - 1), g.rh1) * 2.0f - 1.0f;
+    isnan = isnan || (gx != gx) || (gy != gy);      // non-finite camera tables only
+    gx = clamp_fast(gx, -1.1f, 1.1f);
+    gy = clamp_fast(gy, -1.1f, 1.1f);
+    ix = (gx + 1.0f) * ((float)(g.w - 1) / 2.0f);
+    iy = (gy + 1.0f) * ((float)(g.h - 1) / 2.0f);
+    return bound;
+}
+
 // bilinear weights, ATen CPU form: w = ix - floor(ix), e = 1 - w, ...
 struct Bilin {
     int x0, y0;
@@ -106,6 +205,16 @@ __device__ __forceinline__ float fuse(float acc, float den)
     float o = acc / den;
     if (o != o) o = 0.0f;
     return o < 0.0f ? 0.0f : (o > 1.0f ? 1.0f : o);
+}
+
+// acc / den with rden = RN(1/den): den = (#views seeing the voxel) + 1e-6f takes at most 17 values
+// (SP3D_MAX_VIEWS); the corrected quotient is the IEEE one for each of them (tested like div_const).
+__device__ __forceinline__ float fuse_rcp(float acc, float den, float rden)
+{
+    const float q = acc * rden;
+    const float r = fmaf(-q, den, acc);
+    const float o = fmaf(r, rden, q);
+    return __builtin_amdgcn_fmed3f(o, 0.0f, 1.0f);   // med3(NaN,0,1) = 0: the NaN->0 rule of project_layer.py:98
 }
 
 // blockIdx -> logical tile so that each XCD (observed: block b runs on XCD b % 8) walks a

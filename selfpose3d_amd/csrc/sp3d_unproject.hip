@@ -292,6 +292,193 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// channels-last forward, software-pipelined per wave ("pipe" kernel).
+//
+// A wave owns 64 consecutive voxels and never synchronises with the other waves of its
+// workgroup.  For every view c it alternates two lane mappings:
+//   P1(c)   lane l = voxel l : project through camera c, reduce the sample position to one
+//           record {offset of the 2x2 tap block, 4 slot weights} staged in the wave's LDS slice
+//           (double buffered by view parity).  Taps outside the heat-map (zeros padding) and
+//           voxels not seen by camera c become zero WEIGHTS on in-range addresses, so the gather
+//           is branch free; the 2x2 block is clamped inside the image and the weights move to
+//           the slot whose pixel they belong to (order of the non-zero terms of ATen's
+//           bilinear FMA chain is preserved => same bits as the oracle).
+//   G(c)    lane (g,q) = voxels {g, 16+g, 32+g, 48+g}, channel quad q : 16 dwordx4 loads (each
+//           4-lane group reads 64 contiguous bytes) issued back to back, THEN P1(c+1) runs on the
+//           VALU while they are in flight, then the 64 FMAs of view c.
+// The result tile goes through the wave's LDS slice once and leaves as dwordx4 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int WREC = 2 * 5 * 64;           // floats: [buf][field][voxel]
+constexpr int WOSTR = 68;                  // sOut row stride (floats), rows 16-B aligned
+
+struct Rec {
+    int off;
+    float w00, w10, w01, w11;
+};
+
+template <int JP>
+__device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, int h)
+{
+    Rec r;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float wx = ix - fx0, ex = 1.0f - wx, ny = iy - fy0, sy = 1.0f - ny;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    // clamp the 2x2 block inside the image; d = shift of the block relative to the true taps:
+    //   0: both taps in range; +1: only the right/bottom tap (x0 == -1), it now sits in the
+    //   left/top slot; -1: only the left/top tap (x0 == w-1), now in the right/bottom slot;
+    //   anything else: both taps fall in the zero padding.
+    const int x0c = min(max(x0, 0), w - 2), y0c = min(max(y0, 0), h - 2);
+    const int dxs = use ? x0c - x0 : 99, dys = y0c - y0;
+    const float fxl = dxs == 0 ? ex : (dxs == 1 ? wx : 0.0f);
+    const float fxr = dxs == 0 ? wx : (dxs == -1 ? ex : 0.0f);
+    const float fyt = dys == 0 ? sy : (dys == 1 ? ny : 0.0f);
+    const float fyb = dys == 0 ? ny : (dys == -1 ? sy : 0.0f);
+    r.w00 = fyt * fxl; r.w10 = fyt * fxr; r.w01 = fyb * fxl; r.w11 = fyb * fxr;
+    r.off = (y0c * w + x0c) * JP;
+    return r;
+}
+
+// NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
+template <int JP, bool XCD, int NW>
+__global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
+                                                             const float *__restrict__ centers,
+                                                             const uint8_t *__restrict__ valid,
+                                                             float *__restrict__ cubes, float *__restrict__ grids,
+                                                             Geom g, int tiles_per_sample, int total_tiles)
+{
+    constexpr int NQ = JP / 4;
+    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
+    __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
+
+    int lt = blockIdx.x;
+    if (XCD) {
+        lt = xcd_remap(blockIdx.x, total_tiles);
+        if (lt >= total_tiles) return;
+    }
+    const int b = lt / tiles_per_sample;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = (lt - b * tiles_per_sample) * (64 * NW) + wave * 64;   // first voxel of this wave
+    if (n0 >= g.N) return;
+    const int nvox = min(64, g.N - n0);
+    float *cb = cubes + (size_t)b * g.J * g.N;
+    float *ws = smem + wave * WLDS;
+    int *wsi = reinterpret_cast<int *>(ws);
+
+    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        for (int j = 0; j < g.J; ++j)
+            if (lane < nvox) cb[(size_t)j * g.N + n0 + lane] = 0.0f;
+        if (grids && lane < nvox) {
+            float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
+            gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+        }
+        return;
+    }
+
+    // this lane's voxel (P1 mapping)
+    const bool inb = lane < nvox;
+    const int n = n0 + (inb ? lane : 0);
+    int vx, rem, vy, vz;
+    udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
+    udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
+    const float x = linspace_step(g.Lx, g.stepx, g.X, vx) + centers[3 * b + 0];
+    const float y = linspace_step(g.Ly, g.stepy, g.Y, vy) + centers[3 * b + 1];
+    const float z = linspace_step(g.Lz, g.stepz, g.Z, vz) + centers[3 * b + 2];
+    if (grids && inb) {
+        float *gp = grids + ((size_t)b * g.N + n) * 3;
+        gp[0] = x; gp[1] = y; gp[2] = z;
+    }
+    uint32_t mymask = 0;                        // bound bits of MY voxel (+ bit 31: NaN position)
+
+    auto P1 = [&](int c) -> bool {
+        const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+        float ix, iy;
+        bool isnan;
+        const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
+        if (bound) mymask |= (1u << c);
+        if (isnan && inb) mymask |= 0x80000000u;
+        const bool use = bound && !isnan;
+        if (!__any(use)) return false;          // no voxel of this wave sees camera c
+        const Rec r = make_record<JP>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
+        const int base = (c & 1) * 320 + lane;
+        wsi[base] = r.off;
+        ws[base + 64] = r.w00; ws[base + 128] = r.w10; ws[base + 192] = r.w01; ws[base + 256] = r.w11;
+        return true;
+    };
+
+    // gather mapping
+    const int g16 = lane >> 2, q = lane & 3;
+    const bool qact = q < NQ;
+    const size_t rowf = (size_t)g.w * JP;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
+
+    bool have = P1(0);
+#pragma unroll 1
+    for (int c = 0; c < g.V; ++c) {
+        float4 t00[4], t10[4], t01[4], t11[4];
+        const bool cur = have;
+        if (cur) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *vb = hm.p[c] + (size_t)b * g.h * rowf + (qact ? 4 * q : 0);
+            const int rb = (c & 1) * 320 + g16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *p = vb + wsi[rb + 16 * i];
+                t00[i] = *reinterpret_cast<const float4 *>(p);
+                t10[i] = *reinterpret_cast<const float4 *>(p + JP);
+                t01[i] = *reinterpret_cast<const float4 *>(p + rowf);
+                t11[i] = *reinterpret_cast<const float4 *>(p + rowf + JP);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur) {
+            const int rb = (c & 1) * 320 + g16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
+                const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
+                float v;
+                v = t00[i].x * w00; v = fmaf(t10[i].x, w10, v); v = fmaf(t01[i].x, w01, v); v = fmaf(t11[i].x, w11, v); acc[i][0] = acc[i][0] + v;
+                v = t00[i].y * w00; v = fmaf(t10[i].y, w10, v); v = fmaf(t01[i].y, w01, v); v = fmaf(t11[i].y, w11, v); acc[i][1] = acc[i][1] + v;
+                v = t00[i].z * w00; v = fmaf(t10[i].z, w10, v); v = fmaf(t01[i].z, w01, v); v = fmaf(t11[i].z, w11, v); acc[i][2] = acc[i][2] + v;
+                v = t00[i].w * w00; v = fmaf(t10[i].w, w10, v); v = fmaf(t01[i].w, w01, v); v = fmaf(t11[i].w, w11, v); acc[i][3] = acc[i][3] + v;
+            }
+        }
+    }
+
+    // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = (uint32_t)__shfl((int)mymask, 16 * i + g16);
+        const bool bad = (m & 0x80000000u) != 0;              // NaN sample position: voxel is zero
+        const float den = (float)__popc(m & 0x7fffffffu) + 1e-6f;
+        const float rden = bad ? 0.0f : 1.0f / den;           // rden = 0 makes fuse_rcp return exactly 0
+        if (qact) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (((g.N & 3) == 0) && nvox == 64) {
+        // lane -> (channel j = pass*4 + lane/16, voxel quad u = lane%16): 256 B contiguous per channel
+        for (int j = lane >> 4; j < g.J; j += 4) {
+            const int u = lane & 15;
+            const float4 o = *reinterpret_cast<const float4 *>(&ws[j * WOSTR + 4 * u]);
+            *reinterpret_cast<float4 *>(cb + (size_t)j * g.N + n0 + 4 * u) = o;
+        }
+    } else {
+        for (int j = 0; j < g.J; ++j)
+            if (lane < nvox) cb[(size_t)j * g.N + n0 + lane] = ws[j * WOSTR + lane];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: lane = voxel, planar layout.  Pass 1 recomputes the pre-clamp forward value (the
 // clamp mask: grad flows where 0 <= pre <= 1, torch.clamp backward), pass 2 scatters.
 // ------------------------------------------------------------------------------------------
@@ -401,6 +588,21 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.B = B; g.V = V; g.J = J; g.h = h; g.w = w; g.X = X; g.Y = Y; g.Z = Z;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
+    g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
+    g.rw1 = w > 1 ? 1.0f / (float)(w - 1) : 0.0f; g.rh1 = h > 1 ? 1.0f / (float)(h - 1) : 0.0f;
+    {   // torch.linspace step in fp32: (end - start) / (n - 1) with start = -(L/2), end = L/2
+        const float L[3] = {g.Lx, g.Ly, g.Lz};
+        const int n[3] = {X, Y, Z};
+        float st[3];
+        for (int a = 0; a < 3; ++a) {
+            volatile float start = -(L[a] / 2.0f), end = L[a] / 2.0f;
+            volatile float diff = end - start;
+            st[a] = n[a] > 1 ? diff / (float)(n[a] - 1) : 0.0f;
+        }
+        g.stepx = st[0]; g.stepy = st[1]; g.stepz = st[2];
+    }
+    g.magicYZ = (uint32_t)((0x100000000ull / (uint64_t)(Y * Z)) + 1ull);
+    g.magicZ = (uint32_t)((0x100000000ull / (uint64_t)Z) + 1ull);
     return SP3D_OK;
 }
 
@@ -421,8 +623,10 @@ static int launch_status()
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
-// variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable the XCD-aware tile map
-#define SP3D_DEFAULT_VARIANT 1
+// variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable the XCD-aware tile map;
+// bit 3: per-wave software-pipelined kernel (unproject_pipe_kernel); bit 4: one wave per workgroup
+// default: pipelined kernel; XCD-aware tile map only when several samples share the chip
+#define SP3D_DEFAULT_VARIANT(B) ((B) >= 2 ? 24 : 28)
 
 template <int JP>
 static void launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
@@ -433,6 +637,20 @@ static void launch_nhwc_jp(const Views &v, const float *cam, const float *center
     const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
     const bool xcd = !(variant & 4);
     dim3 grid(xcd ? ((total + 7) / 8) * 8 : total), block(TILE);
+    if (variant & 8) {
+        const int nw = (variant & 16) ? 1 : 4;
+        const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
+        const int ptotal = ptiles * g.B;
+        dim3 pgrid(xcd ? ((ptotal + 7) / 8) * 8 : ptotal), pblock(64 * nw);
+        if (nw == 1) {
+            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+        } else {
+            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 4>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 4>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+        }
+        return;
+    }
 #define SP3D_LAUNCH(XCD_, U_) \
     hipLaunchKernelGGL((unproject_nhwc_kernel<JP, XCD_, U_>), grid, block, lds, s, v, cam, centers, valid, cubes, grids, g, tiles, total)
     switch (variant & 3) {
@@ -447,6 +665,7 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
                        float *cubes, float *grids, const Geom &g, int variant, hipStream_t s)
 {
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
+    if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;   // the clamped 2x2 block needs a 2x2 image
     switch (Jp) {
     case 4: launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
     case 8: launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
@@ -521,7 +740,7 @@ extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, i
             hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         return launch_status();
     }
-    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT, s);
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(B), s);
     return SP3D_EINVAL;
 }
 

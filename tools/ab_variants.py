@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--variants", type=str, default="0,1,2,4,5,6")
+    ap.add_argument("--variants", type=str, default="8,12,24,28")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = [int(v) for v in args.variants.split(",")]
