@@ -43,11 +43,13 @@ def parse():
     ap.add_argument("--roofline-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=6)
+    ap.add_argument("--v2v-layout", choices=["ncdhw", "cl3d"], default="cl3d",
+                    help="memory format of the V2V stack (fp32 either way)")
     ap.add_argument("--cold", action="store_true", help="also time the kernel rotating >256 MiB of inputs (MALL-cold)")
     return ap.parse_args()
 
 
-def build_workload(batch, rank, dev):
+def build_workload(batch, rank, dev, v2v_layout="cl3d"):
     from selfpose3d_amd import synthetic as syn
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
@@ -59,6 +61,8 @@ def build_workload(batch, rank, dev):
     hms = [x.to(dev) for x in syn.random_heatmaps(batch, V, J, h, w, seed=1000 + rank)]
     torch.manual_seed(0)
     model = CuboidProposalNet(cfg).eval().to(dev)
+    if v2v_layout == "cl3d":
+        model.use_channels_last(True)
     return cfg, meta, hms, model
 
 
@@ -185,7 +189,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     torch.backends.cudnn.benchmark = True
-    cfg, meta, hms, model = build_workload(args.batch, rank, dev)
+    cfg, meta, hms, model = build_workload(args.batch, rank, dev, args.v2v_layout)
 
     def step():
         with torch.no_grad():
@@ -224,7 +228,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
                        "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
                        "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
-                       "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(MIOpen fp32) -> NMS/top-k(HIP)"},
+                       "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(MIOpen fp32) -> NMS/top-k(HIP)",
+                       "v2v_layout": args.v2v_layout},
             "views_x_frames_per_s": round(value * V, 3),
         }
         result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, cold=args.cold)

@@ -60,7 +60,10 @@ enum {
 /* heat-map layouts accepted by the unprojection kernels (per-view pointers in both) */
 enum {
     SP3D_LAYOUT_PLANAR = 0,  /* view c: (B, J, h, w) fp32 - the reference's layout (pose_resnet.py:203) */
-    SP3D_LAYOUT_NHWC = 1     /* view c: (B, h, w, Jp) fp32, Jp%4==0, channels >= J are ignored padding */
+    SP3D_LAYOUT_NHWC = 1,    /* view c: (B, h, w, Jp) fp32, Jp%4==0, channels >= J are ignored padding */
+    /* OR-ed into hm_layout: write `cubes` channels-last, (B, X, Y, Z, J) with J%4==0 (NHWC input
+     * only) - the layout MIOpen's 3D convolutions consume without an internal transpose. */
+    SP3D_OUT_CHANNELS_LAST = 0x100
 };
 
 int sp3d_abi_version(void);
@@ -80,7 +83,8 @@ int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V
  *   cam       (B,V,32) camera table            centers (B,3) grid centres, mm
  *   valid     (B) uint8; 0 => sample skipped: its cubes/grids rows are written as zeros
  *             (project_layer.py:48,51,54: `grid_center[i][3] >= 0`)
- *   cubes     (B,J,X,Y,Z) fp32, z fastest       grids (B,X*Y*Z,3) fp32 or NULL (not wanted)
+ *   cubes     (B,J,X,Y,Z) fp32, z fastest [(B,X,Y,Z,J) with SP3D_OUT_CHANNELS_LAST]
+ *   grids     (B,X*Y*Z,3) fp32 or NULL (not wanted)
  *   grid_size HOST float[3] box edge lengths mm; W_in,H_in network input size (cfg IMAGE_SIZE)
  */
 int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam, const float *centers,

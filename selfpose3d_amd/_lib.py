@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsp3d.so")
 
 LAYOUT_PLANAR = 0
 LAYOUT_NHWC = 1
+OUT_CHANNELS_LAST = 0x100
 MAX_VIEWS = 16
 MAX_TOPK = 32
 ABI_VERSION = 1
@@ -111,25 +112,32 @@ def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch
 
 def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
-                  want_grids: bool = True, variant: Optional[int] = None):
+                  want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False):
+    """-> (cubes (B,J,X,Y,Z), grids (B,N,3) | None).  With ``channels_last`` the cubes tensor has
+    torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only)."""
     lib = load()
     dev = cam.device
     _require_cuda(cam, "cam")
     X, Y, Z = (int(c) for c in cube_size)
     V = len(views)
-    cubes = torch.empty((B, J, X, Y, Z), dtype=torch.float32, device=dev)
+    if channels_last:
+        cubes = torch.empty((B, X, Y, Z, J), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
+    else:
+        cubes = torch.empty((B, J, X, Y, Z), dtype=torch.float32, device=dev)
     grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
     gs = _f3(grid_size)
     if variant is None:
-        rc = lib.sp3d_unproject_fwd(_ptr_array(views), layout, jp, cam.data_ptr(), centers.data_ptr(),
-                                    valid.data_ptr(), cubes.data_ptr(), grids.data_ptr() if want_grids else None,
-                                    B, V, J, h, w, X, Y, Z, gs, int(img_size[0]), int(img_size[1]), _stream(dev))
+        rc = lib.sp3d_unproject_fwd(_ptr_array(views), layout | (OUT_CHANNELS_LAST if channels_last else 0), jp,
+                                    cam.data_ptr(), centers.data_ptr(), valid.data_ptr(), cubes.data_ptr(),
+                                    grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
+                                    int(img_size[0]), int(img_size[1]), _stream(dev))
     else:
         assert layout == LAYOUT_NHWC
         rc = lib.sp3d_unproject_fwd_variant(_ptr_array(views), jp, cam.data_ptr(), centers.data_ptr(),
                                             valid.data_ptr(), cubes.data_ptr(),
                                             grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
-                                            int(img_size[0]), int(img_size[1]), int(variant), _stream(dev))
+                                            int(img_size[0]), int(img_size[1]),
+                                            int(variant) | (0x100 if channels_last else 0), _stream(dev))
     check(rc, "sp3d_unproject_fwd")
     return cubes, grids
 
@@ -141,7 +149,7 @@ def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: 
     B, J, h, w = hms[0].shape
     X, Y, Z = (int(c) for c in cube_size)
     V = len(hms)
-    grad_cubes = grad_cubes.contiguous().float()
+    grad_cubes = grad_cubes[:, :J].contiguous().float()
     grads = torch.zeros((V, B, J, h, w), dtype=torch.float32, device=dev)
     gviews = [grads[c] for c in range(V)]
     rc = lib.sp3d_unproject_bwd(_ptr_array(hms), cam.data_ptr(), centers.data_ptr(), valid.data_ptr(),

@@ -339,7 +339,7 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 }
 
 // NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
-template <int JP, bool XCD, int NW>
+template <int JP, bool XCD, int NW, bool OUTCL>
 __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
                                                              const float *__restrict__ centers,
                                                              const uint8_t *__restrict__ valid,
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 
     if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
         for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) cb[(size_t)j * g.N + n0 + lane] = 0.0f;
+            if (lane < nvox) cb[OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)] = 0.0f;
         if (grids && lane < nvox) {
             float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
             gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
@@ -458,11 +458,22 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         const bool bad = (m & 0x80000000u) != 0;              // NaN sample position: voxel is zero
         const float den = (float)__popc(m & 0x7fffffffu) + 1e-6f;
         const float rden = bad ? 0.0f : 1.0f / den;           // rden = 0 makes fuse_rcp return exactly 0
-        if (qact) {
+        if (OUTCL) {
+            // channels-last result (B, N, J): this lane's 4 channels are 16 contiguous bytes, the
+            // 4 lanes of a voxel 64 B, the wave's 16 voxels of slot i 1 KiB - no LDS transpose.
+            const int nn = 16 * i + g16;
+            if (qact && 4 * q < g.J && nn < nvox) {
+                float4 o;
+                o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
+                o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
+                *reinterpret_cast<float4 *>(cb + (size_t)(n0 + nn) * g.J + 4 * q) = o;
+            }
+        } else if (qact) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
         }
     }
+    if (OUTCL) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (((g.N & 3) == 0) && nvox == 64) {
@@ -629,8 +640,8 @@ static int launch_status()
 #define SP3D_DEFAULT_VARIANT(B) ((B) >= 2 ? 24 : 28)
 
 template <int JP>
-static void launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
-                           float *grids, const Geom &g, int variant, hipStream_t s)
+static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
+                          float *grids, const Geom &g, int variant, bool out_cl, hipStream_t s)
 {
     const int tiles = (g.N + TILE - 1) / TILE;
     const int total = tiles * g.B;
@@ -642,15 +653,19 @@ static void launch_nhwc_jp(const Views &v, const float *cam, const float *center
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
         const int ptotal = ptiles * g.B;
         dim3 pgrid(xcd ? ((ptotal + 7) / 8) * 8 : ptotal), pblock(64 * nw);
-        if (nw == 1) {
-            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+#define SP3D_PIPE(XCD_, NW_, CL_) \
+    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
+        if (out_cl) {
+            if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, true); else SP3D_PIPE(false, 1, true); }
+            else { if (xcd) SP3D_PIPE(true, 4, true); else SP3D_PIPE(false, 4, true); }
         } else {
-            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 4>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 4>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, false); else SP3D_PIPE(false, 1, false); }
+            else { if (xcd) SP3D_PIPE(true, 4, false); else SP3D_PIPE(false, 4, false); }
         }
-        return;
+#undef SP3D_PIPE
+        return SP3D_OK;
     }
+    if (out_cl) return SP3D_EUNSUPPORTED;
 #define SP3D_LAUNCH(XCD_, U_) \
     hipLaunchKernelGGL((unproject_nhwc_kernel<JP, XCD_, U_>), grid, block, lds, s, v, cam, centers, valid, cubes, grids, g, tiles, total)
     switch (variant & 3) {
@@ -659,21 +674,24 @@ static void launch_nhwc_jp(const Views &v, const float *cam, const float *center
     default: if (xcd) SP3D_LAUNCH(true, 2); else SP3D_LAUNCH(false, 2); break;
     }
 #undef SP3D_LAUNCH
+    return SP3D_OK;
 }
 
 static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *centers, const uint8_t *valid,
-                       float *cubes, float *grids, const Geom &g, int variant, hipStream_t s)
+                       float *cubes, float *grids, const Geom &g, int variant, bool out_cl, hipStream_t s)
 {
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
-    if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;   // the clamped 2x2 block needs a 2x2 image
+    if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
+    if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;    // the clamped 2x2 block needs a 2x2 image
+    int rc;
     switch (Jp) {
-    case 4: launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
-    case 8: launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
-    case 12: launch_nhwc_jp<12>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
-    case 16: launch_nhwc_jp<16>(v, cam, centers, valid, cubes, grids, g, variant, s); break;
+    case 4: rc = launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
+    case 8: rc = launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
+    case 12: rc = launch_nhwc_jp<12>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
+    case 16: rc = launch_nhwc_jp<16>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
     default: return SP3D_EUNSUPPORTED;
     }
-    return launch_status();
+    return rc ? rc : launch_status();
 }
 
 } // namespace sp3d
@@ -730,7 +748,10 @@ extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, i
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g.N + TILE - 1) / TILE;
+    const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
+    hm_layout &= 0xff;
     if (hm_layout == SP3D_LAYOUT_PLANAR) {
+        if (out_cl) return SP3D_EUNSUPPORTED;
         dim3 grid(tiles, B), block(TILE);
         if (J == 1)
             hipLaunchKernelGGL(unproject_planar_kernel<1>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
@@ -740,7 +761,7 @@ extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, i
             hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         return launch_status();
     }
-    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(B), s);
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(B), out_cl, s);
     return SP3D_EINVAL;
 }
 
@@ -787,5 +808,5 @@ extern "C" int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, 
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
-    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant, (hipStream_t)stream);
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & 0xff, (variant & 0x100) != 0, (hipStream_t)stream);
 }

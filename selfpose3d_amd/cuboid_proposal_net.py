@@ -60,6 +60,13 @@ class CuboidProposalNet(nn.Module):
         self.project_layer = ProjectLayer(cfg)
         self.v2v_net = V2VNet(1 if self.rootnet_roothm else int(cfg.NETWORK.NUM_JOINTS), 1)
         self.proposal_layer = ProposalLayer(cfg)
+        self.channels_last = False      # set by use_channels_last()
+
+    def use_channels_last(self, on: bool = True):
+        """run the V2V stack in torch.channels_last_3d (MIOpen NDHWC kernels, no internal transposes)"""
+        self.channels_last = bool(on)
+        self.v2v_net.to(memory_format=torch.channels_last_3d if on else torch.contiguous_format)
+        return self
 
     def forward(self, all_heatmaps, meta, flip_xcoords=None):
         if self.rootnet_roothm:                                   # root-joint channel only (:103-108)
@@ -67,6 +74,7 @@ class CuboidProposalNet(nn.Module):
         else:
             hms = all_heatmaps
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
-                                                flip_xcoords=flip_xcoords, want_grids=False)
+                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=True,
+                                                channels_last=self.channels_last)
         root_cubes = self.v2v_net(cubes).squeeze(1)
         return root_cubes, self.proposal_layer(root_cubes, meta)

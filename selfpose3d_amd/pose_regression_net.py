@@ -36,13 +36,20 @@ class PoseRegressionNet(nn.Module):
         self.project_layer = ProjectLayer(cfg)
         self.v2v_net = V2VNet(int(cfg.NETWORK.NUM_JOINTS), int(cfg.NETWORK.NUM_JOINTS))
         self.soft_argmax_layer = SoftArgmaxLayer(cfg)
+        self.channels_last = False
+
+    def use_channels_last(self, on: bool = True):
+        self.channels_last = bool(on)
+        self.v2v_net.to(memory_format=torch.channels_last_3d if on else torch.contiguous_format)
+        return self
 
     def forward(self, all_heatmaps, meta, grid_centers, flip_xcoords=None):
         B, J = all_heatmaps[0].shape[:2]
         device = all_heatmaps[0].device
         pred = torch.zeros(B, J, 3, device=device)
-        cubes, grids = self.project_layer(all_heatmaps, meta, self.grid_size, grid_centers, self.cube_size,
-                                          flip_xcoords=flip_xcoords)
+        cubes, grids = self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, grid_centers, self.cube_size,
+                                                    flip_xcoords=flip_xcoords, pad_channels=True,
+                                                    channels_last=self.channels_last)
         index = grid_centers[:, 3] >= 0
         if bool(index.any()):
             valid_cubes = self.v2v_net(cubes[index])

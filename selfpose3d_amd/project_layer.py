@@ -26,15 +26,20 @@ class _UnprojectFn(torch.autograd.Function):
     """autograd seam: gradient flows to the heat-maps only."""
 
     @staticmethod
-    def forward(ctx, layer, cam, centers, valid, grid_size, cube_size, want_grids, mode, *heatmaps):
+    def forward(ctx, layer, cam, centers, valid, grid_size, cube_size, want_grids, mode, pad_channels, channels_last,
+                *heatmaps):
         B, J, h, w = heatmaps[0].shape
         hms = [x.detach() for x in heatmaps]
         hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
         if mode == "nhwc":
             packed = _lib.pack_heatmaps(hms, jp=layer.jp_for(J))
+            jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
-            cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, packed.shape[-1], cam, centers, valid, B, J, h,
-                                              w, cube_size, grid_size, layer.img_size, want_grids)
+            # pad_channels: run the kernel over all jp channels - the padded ones are zero in `packed`,
+            # so the extra output channels are exact zeros at no extra cost
+            cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, B,
+                                              jp if pad_channels else J, h, w, cube_size, grid_size, layer.img_size,
+                                              want_grids, channels_last=channels_last)
         else:
             cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
                                               grid_size, layer.img_size, want_grids)
@@ -51,7 +56,7 @@ class _UnprojectFn(torch.autograd.Function):
         cam, centers, valid, *hms = ctx.saved_tensors
         grid_size, cube_size = ctx.geom
         grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size)
-        return (None,) * 8 + tuple(grads)
+        return (None,) * 10 + tuple(grads)
 
 
 class ProjectLayer(nn.Module):
@@ -100,7 +105,12 @@ class ProjectLayer(nn.Module):
         return centers.contiguous(), valid.contiguous()
 
     # -- reference API -------------------------------------------------------------------
-    def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True):
+    def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True,
+                  pad_channels=False, channels_last=False):
+        """Reference semantics (project_layer.py:42-102).  Extras for in-repo callers only:
+        ``want_grids=False`` skips the (B,N,3) grid output, ``pad_channels`` returns
+        ceil4(J) channels (zeros beyond J) and ``channels_last`` returns torch.channels_last_3d
+        strides - both let MIOpen's 3D convolutions run their fast paths without a copy."""
         device = heatmaps[0].device
         if not heatmaps[0].is_cuda:
             raise _lib.Sp3dError("ProjectLayer: heat-maps must be on the GPU (no CPU fallback)")
@@ -116,9 +126,14 @@ class ProjectLayer(nn.Module):
             grid_size = [grid_size] * 3
         mode = self.mode
         if mode == "auto":
-            mode = "nhwc" if J <= 16 else "planar"
+            mode = "nhwc" if (J <= 16 and w >= 2 and h >= 2) else "planar"
+        if mode != "nhwc":
+            pad_channels = channels_last = False
+        if channels_last and not pad_channels and (J & 3):
+            channels_last = False
         cubes, grids = _UnprojectFn.apply(self, cam, centers, valid, [float(v) for v in grid_size],
-                                          [int(v) for v in cube_size], bool(want_grids), mode, *heatmaps)
+                                          [int(v) for v in cube_size], bool(want_grids), mode, bool(pad_channels),
+                                          bool(channels_last), *heatmaps)
         return cubes, (grids if want_grids else None)
 
     def forward(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None):

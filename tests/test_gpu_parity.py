@@ -300,3 +300,46 @@ def test_rootnet_posenet_vs_reference_golden(dev):
             pred = posenet(hms, meta, gc_ref[:, n].to(dev))
             assert float((pred.cpu() - torch.from_numpy(g["preds"][n])).abs().max()) <= 0.5   # mm
     torch.backends.cudnn.allow_tf32 = prev
+
+
+def test_padded_and_channels_last_outputs(dev):
+    """pad_channels / channels_last are layout-only options: same voxel bits, zeros in the padding"""
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    for name in ("unproj_coarse_full_96x72", "unproj_fine_small", "unproj_coarse_aug"):
+        case = gio.Case(name)
+        cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+        layer = ProjectLayer(cfg)
+        gc = case.grid_center if isinstance(case.grid_center, list) else case.grid_center.to(dev)
+        hms = [h.to(dev) for h in case.hms]
+        base, _ = layer.get_voxel(hms, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip)
+        for pad, cl in ((True, False), (True, True)):
+            got, _ = layer.get_voxel(hms, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip,
+                                     want_grids=False, pad_channels=pad, channels_last=cl)
+            jp = ProjectLayer.jp_for(case.J)
+            assert got.shape == (case.B, jp, *case.cube)
+            if cl:
+                assert got.is_contiguous(memory_format=torch.channels_last_3d)
+            assert torch.equal(got[:, :case.J], base)
+            assert torch.count_nonzero(got[:, case.J:]) == 0
+
+
+def test_rootnet_channels_last_matches_default(dev):
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[384, 288], NETWORK__HEATMAP_SIZE=[96, 72],
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[24, 24, 8])
+    B, V, J = 2, 5, 15
+    meta = syn.make_meta(B, V, (384, 288))
+    hms, _ = syn.people_heatmaps(B, V, J, 72, 96, (384, 288), seed=5)
+    hms = [h.to(dev) for h in hms]
+    net = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=3, scale=0.05)
+    net.eval().to(dev)
+    with torch.no_grad():
+        rc0, gc0 = net(hms, meta)
+        net.use_channels_last(True)
+        rc1, gc1 = net(hms, meta)
+    assert float((rc0 - rc1).abs().max()) <= 2e-4
+    assert torch.equal(gc0[:, :3, :3], gc1[:, :3, :3])
