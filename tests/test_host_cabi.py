@@ -141,3 +141,25 @@ def test_v2v_matches_reference_golden_on_cpu():
     with torch.no_grad():
         y = m(x)
     assert float((y - torch.from_numpy(g["out"])).abs().max()) <= 1e-5
+
+
+def _fma32(a, b, c):
+    # products of two fp32 are exact in fp64; the sum is rounded once to fp64 then to fp32
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def test_const_division_is_exact():
+    """div_const / fuse_rcp of csrc/sp3d_device.h: q=x*rc; r=fma(-q,c,x); q'=fma(r,rc,q) equals IEEE x/c
+    for every constant the kernels divide by (image sizes, heat-map sizes - 1, view counts + 1e-6)."""
+    rng = np.random.default_rng(0)
+    consts = [960, 512, 239, 127, 384, 288, 95, 71, 192, 144, 47, 35, 96, 72, 23, 17, 1920, 1080, 320, 79, 63]
+    consts += [float(np.float32(k) + np.float32(1e-6)) for k in range(1, 17)]
+    for c in consts:
+        cf = np.float32(c)
+        rc = np.float32(1.0) / cf
+        for scale in (1.0, 16.0, 2000.0):
+            x = ((rng.random(400_000, dtype=np.float32) * 2 - 1) * np.float32(scale)).astype(np.float32)
+            q = x * rc
+            r = _fma32(-q, np.full_like(q, cf), x)
+            q1 = _fma32(r, np.full_like(q, rc), q)
+            assert np.array_equal(q1, (x / cf).astype(np.float32)), c
