@@ -92,6 +92,18 @@ int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, cons
                        int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream);
 
 /*
+ * Same as sp3d_unproject_fwd for P output cubes that read from a batch of B <= P samples: cube p
+ * samples the heat-maps / camera rows of sample `sample_of[p]` (device int32[P]; NULL = identity).
+ * This is how the <= MAX_PEOPLE_NUM per-person fine grids of one batch are produced in ONE launch
+ * instead of the reference's per-candidate loop (lib/models/multi_person_posenet.py:84-88 calling
+ * pose_regression_net.py:46).  centers (P,3), valid (P), cubes (P,J,X,Y,Z), grids (P,N,3)|NULL.
+ */
+int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                               const int32_t *sample_of, const float *centers, const uint8_t *valid, float *cubes,
+                               float *grids, int P, int V, int J, int h, int w, int X, int Y, int Z,
+                               const float *grid_size, int W_in, int H_in, void *stream);
+
+/*
  * Gradient of get_voxel w.r.t. the heat-maps (autograd of project_layer.py:93-99;
  * cameras/grids never need gradients: proposals are detached, cuboid_proposal_net.py:57-59).
  *   hm_views      planar heat-maps of the forward pass (needed for the clamp mask)
@@ -103,6 +115,11 @@ int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, cons
 int sp3d_unproject_bwd(const float *const *hm_views, const float *cam, const float *centers, const uint8_t *valid,
                        const float *grad_cubes, float *const *grad_hm_views, int B, int V, int J, int h, int w,
                        int X, int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream);
+
+int sp3d_unproject_bwd_indexed(const float *const *hm_views, const float *cam, const int32_t *sample_of,
+                               const float *centers, const uint8_t *valid, const float *grad_cubes,
+                               float *const *grad_hm_views, int P, int V, int J, int h, int w, int X, int Y, int Z,
+                               const float *grid_size, int W_in, int H_in, void *stream);
 
 /*
  * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,
@@ -122,6 +139,10 @@ int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z, int k, co
  */
 int sp3d_soft_argmax(const float *x, const float *grids, float *out, int Bv, int J, int64_t N, float beta,
                      void *stream);
+/* same result with the voxel centres regenerated from (centers (Bv,3), grid_size, X,Y,Z) - the
+ * values compute_grid (project_layer.py:22-40) would have produced - instead of read from `grids` */
+int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                          float *out, int Bv, int J, float beta, void *stream);
 
 #ifdef __cplusplus
 }

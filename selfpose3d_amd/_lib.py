@@ -24,7 +24,8 @@ ABI_VERSION = 1
 
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
-    "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax",
+    "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
+    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid",
 ]
 
 _lib = None
@@ -60,6 +61,12 @@ def load():
     lib.sp3d_nms_topk.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, V]
     lib.sp3d_soft_argmax.restype = I
     lib.sp3d_soft_argmax.argtypes = [P, P, P, I, I, C.c_int64, F, V]
+    lib.sp3d_unproject_fwd_indexed.restype = I
+    lib.sp3d_unproject_fwd_indexed.argtypes = [P, I, I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_unproject_bwd_indexed.restype = I
+    lib.sp3d_unproject_bwd_indexed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_soft_argmax_grid.restype = I
+    lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
     if hasattr(lib, "sp3d_unproject_fwd_variant"):
         lib.sp3d_unproject_fwd_variant.restype = I
         lib.sp3d_unproject_fwd_variant.argtypes = [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, V]
@@ -112,9 +119,11 @@ def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch
 
 def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
-                  want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False):
+                  want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False,
+                  sample_of: Optional[torch.Tensor] = None):
     """-> (cubes (B,J,X,Y,Z), grids (B,N,3) | None).  With ``channels_last`` the cubes tensor has
-    torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only)."""
+    torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only).
+    ``sample_of`` (int32, (B,)): output cube p reads heat-map/camera row sample_of[p] (B = #cubes)."""
     lib = load()
     dev = cam.device
     _require_cuda(cam, "cam")
@@ -127,10 +136,11 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
     grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
     gs = _f3(grid_size)
     if variant is None:
-        rc = lib.sp3d_unproject_fwd(_ptr_array(views), layout | (OUT_CHANNELS_LAST if channels_last else 0), jp,
-                                    cam.data_ptr(), centers.data_ptr(), valid.data_ptr(), cubes.data_ptr(),
-                                    grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
-                                    int(img_size[0]), int(img_size[1]), _stream(dev))
+        rc = lib.sp3d_unproject_fwd_indexed(_ptr_array(views), layout | (OUT_CHANNELS_LAST if channels_last else 0),
+                                            jp, cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
+                                            centers.data_ptr(), valid.data_ptr(), cubes.data_ptr(),
+                                            grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
+                                            int(img_size[0]), int(img_size[1]), _stream(dev))
     else:
         assert layout == LAYOUT_NHWC
         rc = lib.sp3d_unproject_fwd_variant(_ptr_array(views), jp, cam.data_ptr(), centers.data_ptr(),
@@ -143,18 +153,20 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
 
 
 def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: torch.Tensor, cube_size, grid_size,
-                  img_size):
+                  img_size, sample_of: Optional[torch.Tensor] = None):
     lib = load()
     dev = cam.device
     B, J, h, w = hms[0].shape
+    P = int(grad_cubes.shape[0])
     X, Y, Z = (int(c) for c in cube_size)
     V = len(hms)
     grad_cubes = grad_cubes[:, :J].contiguous().float()
     grads = torch.zeros((V, B, J, h, w), dtype=torch.float32, device=dev)
     gviews = [grads[c] for c in range(V)]
-    rc = lib.sp3d_unproject_bwd(_ptr_array(hms), cam.data_ptr(), centers.data_ptr(), valid.data_ptr(),
-                                grad_cubes.data_ptr(), _ptr_array(gviews), B, V, J, h, w, X, Y, Z, _f3(grid_size),
-                                int(img_size[0]), int(img_size[1]), _stream(dev))
+    rc = lib.sp3d_unproject_bwd_indexed(_ptr_array(hms), cam.data_ptr(),
+                                        sample_of.data_ptr() if sample_of is not None else None, centers.data_ptr(),
+                                        valid.data_ptr(), grad_cubes.data_ptr(), _ptr_array(gviews), P, V, J, h, w, X,
+                                        Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
     check(rc, "sp3d_unproject_bwd")
     return gviews
 
@@ -191,4 +203,20 @@ def soft_argmax(x: torch.Tensor, grids: torch.Tensor, beta: float) -> torch.Tens
         return out
     check(lib.sp3d_soft_argmax(xc.data_ptr(), gc.data_ptr(), out.data_ptr(), Bv, J, N, float(beta), _stream(x.device)),
           "sp3d_soft_argmax")
+    return out
+
+
+def soft_argmax_grid(x: torch.Tensor, centers: torch.Tensor, grid_size, cube_size, beta: float) -> torch.Tensor:
+    """soft-argmax with voxel centres regenerated in-kernel: x (P,J,X,Y,Z), centers (P,3) -> (P,J,3)"""
+    lib = load()
+    _require_cuda(x, "x")
+    P, J = x.shape[:2]
+    X, Y, Z = (int(c) for c in cube_size)
+    xc = x.contiguous().float()
+    cc = centers.contiguous().float()
+    out = torch.empty((P, J, 3), dtype=torch.float32, device=x.device)
+    if P == 0:
+        return out
+    check(lib.sp3d_soft_argmax_grid(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(), P, J,
+                                    float(beta), _stream(x.device)), "sp3d_soft_argmax_grid")
     return out

@@ -30,6 +30,7 @@ struct Geom {
     float rW_in, rH_in, rw1, rh1; // correctly rounded 1/W_in, 1/H_in, 1/(w-1), 1/(h-1)
     float stepx, stepy, stepz;    // fp32 (end-start)/(n-1) of torch.linspace, computed on the host (same IEEE ops)
     uint32_t magicYZ, magicZ;     // floor(2^32/d)+1 for d = Y*Z, Z (exact n/d with one fix-up, see udiv_magic)
+    const int *sample_of;         // optional (P): heat-map / camera row each output cube reads (NULL: identity)
 };
 
 // torch.linspace(-L/2, L/2, n)[i] in fp32 (project_layer.py:28-30; ATen CPU kernel form)

@@ -172,14 +172,30 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// GRID = true: voxel centres are regenerated from (centre, size, bins) exactly as the unprojection
+// kernel writes them (same fp32 linspace form), so `grids` (12 B/voxel) is never materialised.
+struct GridSpec {
+    int X, Y, Z;
+    float Lx, Ly, Lz, sx, sy, sz;   // box size and fp32 linspace steps (host-computed)
+};
+
+__device__ __forceinline__ float lin_at(float L, float step, int n, int i)
+{
+    const float start = -(L / 2.0f), end = L / 2.0f;
+    if (n == 1) return start;
+    return (i < n / 2) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(n - 1 - i), end);
+}
+
+template <bool GRID>
 __global__ __launch_bounds__(SA_THREADS) void soft_argmax_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ grids,
+                                                                const float *__restrict__ centers, GridSpec gs,
                                                                 float *__restrict__ out, int J, int64_t N, float beta)
 {
     __shared__ float red[4][SA_THREADS / 64];
     const int j = blockIdx.x, b = blockIdx.y;
     const float *xv = x + ((size_t)b * J + j) * N;
-    const float *gv = grids + (size_t)b * N * 3;
+    const float *gv = GRID ? nullptr : grids + (size_t)b * N * 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float m = -INFINITY;
     for (int64_t n = threadIdx.x; n < N; n += SA_THREADS) m = fmaxf(m, beta * xv[n]);
@@ -190,13 +206,26 @@ __global__ __launch_bounds__(SA_THREADS) void soft_argmax_kernel(const float *__
 #pragma unroll
     for (int w = 1; w < SA_THREADS / 64; ++w) m = fmaxf(m, red[0][w]);
     __syncthreads();
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (GRID) { cx = centers[3 * b]; cy = centers[3 * b + 1]; cz = centers[3 * b + 2]; }
+    const int YZ = gs.Y * gs.Z;
     float s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int64_t n = threadIdx.x; n < N; n += SA_THREADS) {
         const float e = __expf(beta * xv[n] - m);
+        float g0, g1, g2;
+        if (GRID) {
+            const int nn = (int)n;
+            const int ix = nn / YZ, r = nn - ix * YZ, iy = r / gs.Z, iz = r - iy * gs.Z;
+            g0 = lin_at(gs.Lx, gs.sx, gs.X, ix) + cx;
+            g1 = lin_at(gs.Ly, gs.sy, gs.Y, iy) + cy;
+            g2 = lin_at(gs.Lz, gs.sz, gs.Z, iz) + cz;
+        } else {
+            g0 = gv[3 * n + 0]; g1 = gv[3 * n + 1]; g2 = gv[3 * n + 2];
+        }
         s += e;
-        a0 = fmaf(e, gv[3 * n + 0], a0);
-        a1 = fmaf(e, gv[3 * n + 1], a1);
-        a2 = fmaf(e, gv[3 * n + 2], a2);
+        a0 = fmaf(e, g0, a0);
+        a1 = fmaf(e, g1, a1);
+        a2 = fmaf(e, g2, a2);
     }
     s = wave_sum(s); a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane == 0) { red[0][wave] = s; red[1][wave] = a0; red[2][wave] = a1; red[3][wave] = a2; }
@@ -249,8 +278,32 @@ extern "C" int sp3d_soft_argmax(const float *x, const float *grids, float *out, 
 {
     if (Bv <= 0 || J <= 0 || N <= 0) return SP3D_EINVAL;
     if (!x || !grids || !out) return SP3D_ENULL;
-    hipLaunchKernelGGL(soft_argmax_kernel, dim3(J, Bv), dim3(SA_THREADS), 0, (hipStream_t)stream, x, grids, out, J, N,
-                       beta);
+    GridSpec gs = {};
+    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3(J, Bv), dim3(SA_THREADS), 0, (hipStream_t)stream, x, grids,
+                       (const float *)nullptr, gs, out, J, N, beta);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                                     float *out, int Bv, int J, float beta, void *stream)
+{
+    if (Bv <= 0 || J <= 0 || X <= 0 || Y <= 0 || Z <= 0) return SP3D_EINVAL;
+    if (!x || !centers || !grid_size || !out) return SP3D_ENULL;
+    const int64_t N = (int64_t)X * Y * Z;
+    if (N > 0x7ffffffe) return SP3D_ERANGE;
+    GridSpec gs;
+    gs.X = X; gs.Y = Y; gs.Z = Z; gs.Lx = grid_size[0]; gs.Ly = grid_size[1]; gs.Lz = grid_size[2];
+    const int n[3] = {X, Y, Z};
+    float st[3];
+    for (int a = 0; a < 3; ++a) {
+        volatile float start = -(grid_size[a] / 2.0f), end = grid_size[a] / 2.0f;
+        volatile float diff = end - start;
+        st[a] = n[a] > 1 ? diff / (float)(n[a] - 1) : 0.0f;
+    }
+    gs.sx = st[0]; gs.sy = st[1]; gs.sz = st[2];
+    hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3(J, Bv), dim3(SA_THREADS), 0, (hipStream_t)stream, x,
+                       (const float *)nullptr, centers, gs, out, J, N, beta);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

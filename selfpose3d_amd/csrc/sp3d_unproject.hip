@@ -35,6 +35,7 @@ __global__ __launch_bounds__(TILE) void unproject_planar_kernel(Views hm, const 
                                                                Geom g)
 {
     const int b = blockIdx.y;
+    const int bs = g.sample_of ? g.sample_of[b] : b;   // row of the heat-map batch / camera table this cube reads
     const int n = blockIdx.x * TILE + threadIdx.x;
     if (n >= g.N) return;
     float *cb = cubes + (size_t)b * g.J * g.N;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(TILE) void unproject_planar_kernel(Views hm, const 
         float cnt = 0.0f;
         bool bad = false;
         for (int c = 0; c < g.V; ++c) {
-            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
             float ix, iy;
             const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
             cnt += bound ? 1.0f : 0.0f;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(TILE) void unproject_planar_kernel(Views hm, const 
             const Bilin bl = bilin(ix, iy);
             const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
             const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
-            const float *base = hm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+            const float *base = hm.p[c] + ((size_t)bs * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
 #pragma unroll
             for (int k = 0; k < JC; ++k) {
                 if (j0 + k < g.J) {
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
         if (lt >= total_tiles) return;
     }
     const int b = lt / tiles_per_sample;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
     const int n0 = (lt - b * tiles_per_sample) * TILE;
     const int tid = threadIdx.x;
     const int nvox = min(TILE, g.N - n0);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
             }
             const float W_in = (float)g.W_in, H_in = (float)g.H_in;
             for (int c = 0; c < g.V; ++c) {
-                const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+                const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
                 float ix, iy;
                 const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
                 if (bound) mask |= (1u << c);
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
 #pragma unroll 1
             for (int c = 0; c < g.V; ++c) {
                 if (!__any((any >> c) & 1u)) continue;         // wave-uniform skip
-                const float *vb = hm.p[c] + (size_t)b * g.h * rowf + 4 * q;
+                const float *vb = hm.p[c] + (size_t)bs * g.h * rowf + 4 * q;
                 float4 t00[U], t10[U], t01[U], t11[U];
                 float wnw[U], wne[U], wsw[U], wse[U];
                 // Branch-free gather: every lane always loads.  A tap outside the heat-map (zeros
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         if (lt >= total_tiles) return;
     }
     const int b = lt / tiles_per_sample;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = (lt - b * tiles_per_sample) * (64 * NW) + wave * 64;   // first voxel of this wave
     if (n0 >= g.N) return;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     uint32_t mymask = 0;                        // bound bits of MY voxel (+ bit 31: NaN position)
 
     auto P1 = [&](int c) -> bool {
-        const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+        const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
         float ix, iy;
         bool isnan;
         const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const float *vb = hm.p[c] + (size_t)b * g.h * rowf + (qact ? 4 * q : 0);
+            const float *vb = hm.p[c] + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
             const int rb = (c & 1) * 320 + g16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
                                                             Geom g)
 {
     const int b = blockIdx.y;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
     const int n = blockIdx.x * TILE + threadIdx.x;
     if (n >= g.N || !valid[b]) return;
     const int vx = n / g.YZ, rem = n - vx * g.YZ, vy = rem / g.Z, vz = rem - vy * g.Z;
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
         float cnt = 0.0f;
         bool bad = false;
         for (int c = 0; c < g.V; ++c) {
-            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
             float ix, iy;
             const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
             cnt += bound ? 1.0f : 0.0f;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
             const Bilin bl = bilin(ix, iy);
             const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
             const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
-            const float *base = hm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+            const float *base = hm.p[c] + ((size_t)bs * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
 #pragma unroll
             for (int k = 0; k < JC; ++k) {
                 if (j0 + k < g.J) {
@@ -560,14 +564,14 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
         }
         if (!anyg) continue;
         for (int c = 0; c < g.V; ++c) {
-            const float *cm = cam + ((size_t)b * g.V + c) * SP3D_CAM_STRIDE;
+            const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
             float ix, iy;
             const bool bound = sample_pos(cm, x, y, z, g.w, g.h, W_in, H_in, ix, iy);
             if (!bound) continue;
             const Bilin bl = bilin(ix, iy);
             const bool x0ok = bl.x0 >= 0 && bl.x0 <= g.w - 1, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 <= g.w - 1;
             const bool y0ok = bl.y0 >= 0 && bl.y0 <= g.h - 1, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 <= g.h - 1;
-            float *base = ghm.p[c] + ((size_t)b * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
+            float *base = ghm.p[c] + ((size_t)bs * g.J + j0) * plane + (ptrdiff_t)bl.y0 * g.w + bl.x0;
 #pragma unroll
             for (int k = 0; k < JC; ++k) {
                 if (j0 + k < g.J && gs[k] != 0.0f) {
@@ -597,6 +601,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     if ((int64_t)B * ((N + TILE - 1) / TILE) > (int64_t)0x7fffffff - 8) return SP3D_ERANGE;
     if ((int64_t)h * w * 16 > (int64_t)0x7fffffff) return SP3D_ERANGE;
     g.B = B; g.V = V; g.J = J; g.h = h; g.w = w; g.X = X; g.Y = Y; g.Z = Z;
+    g.sample_of = nullptr;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
     g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
@@ -734,15 +739,16 @@ extern "C" int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, i
     return launch_status();
 }
 
-extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
-                                  const float *centers, const uint8_t *valid, float *cubes, float *grids, int B,
-                                  int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
-                                  int H_in, void *stream)
+extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                                          const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                                          float *cubes, float *grids, int P, int V, int J, int h, int w, int X, int Y,
+                                          int Z, const float *grid_size, int W_in, int H_in, void *stream)
 {
     Geom g;
-    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
     if (rc) return rc;
     if (!cam || !centers || !valid || !cubes) return SP3D_ENULL;
+    g.sample_of = sample_of;
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
@@ -752,7 +758,7 @@ extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, i
     hm_layout &= 0xff;
     if (hm_layout == SP3D_LAYOUT_PLANAR) {
         if (out_cl) return SP3D_EUNSUPPORTED;
-        dim3 grid(tiles, B), block(TILE);
+        dim3 grid(tiles, P), block(TILE);
         if (J == 1)
             hipLaunchKernelGGL(unproject_planar_kernel<1>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         else if (J <= 4)
@@ -761,19 +767,29 @@ extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, i
             hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         return launch_status();
     }
-    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(B), out_cl, s);
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(P), out_cl, s);
     return SP3D_EINVAL;
 }
 
-extern "C" int sp3d_unproject_bwd(const float *const *hm_views, const float *cam, const float *centers,
-                                  const uint8_t *valid, const float *grad_cubes, float *const *grad_hm_views, int B,
+extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                                  const float *centers, const uint8_t *valid, float *cubes, float *grids, int B,
                                   int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
                                   int H_in, void *stream)
 {
+    return sp3d_unproject_fwd_indexed(hm_views, hm_layout, Jp, cam, nullptr, centers, valid, cubes, grids, B, V, J, h,
+                                      w, X, Y, Z, grid_size, W_in, H_in, stream);
+}
+
+extern "C" int sp3d_unproject_bwd_indexed(const float *const *hm_views, const float *cam, const int32_t *sample_of,
+                                          const float *centers, const uint8_t *valid, const float *grad_cubes,
+                                          float *const *grad_hm_views, int P, int V, int J, int h, int w, int X, int Y,
+                                          int Z, const float *grid_size, int W_in, int H_in, void *stream)
+{
     Geom g;
-    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
     if (rc) return rc;
     if (!cam || !centers || !valid || !grad_cubes || !grad_hm_views) return SP3D_ENULL;
+    g.sample_of = sample_of;
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
@@ -784,7 +800,7 @@ extern "C" int sp3d_unproject_bwd(const float *const *hm_views, const float *cam
         gv.p[c] = grad_hm_views[c];
     }
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((g.N + TILE - 1) / TILE, B), block(TILE);
+    dim3 grid((g.N + TILE - 1) / TILE, P), block(TILE);
     if (J == 1)
         hipLaunchKernelGGL(unproject_bwd_kernel<1>, grid, block, 0, s, v, cam, centers, valid, grad_cubes, gv, g);
     else if (J <= 4)
@@ -792,6 +808,15 @@ extern "C" int sp3d_unproject_bwd(const float *const *hm_views, const float *cam
     else
         hipLaunchKernelGGL(unproject_bwd_kernel<16>, grid, block, 0, s, v, cam, centers, valid, grad_cubes, gv, g);
     return launch_status();
+}
+
+extern "C" int sp3d_unproject_bwd(const float *const *hm_views, const float *cam, const float *centers,
+                                  const uint8_t *valid, const float *grad_cubes, float *const *grad_hm_views, int B,
+                                  int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
+                                  int H_in, void *stream)
+{
+    return sp3d_unproject_bwd_indexed(hm_views, cam, nullptr, centers, valid, grad_cubes, grad_hm_views, B, V, J, h, w,
+                                      X, Y, Z, grid_size, W_in, H_in, stream);
 }
 
 // Not part of the drop-in ABI (declared in csrc/sp3d_tuning.h): same as sp3d_unproject_fwd for

@@ -43,6 +43,37 @@ class PoseRegressionNet(nn.Module):
         self.v2v_net.to(memory_format=torch.channels_last_3d if on else torch.contiguous_format)
         return self
 
+    @torch.no_grad()
+    def forward_batched(self, all_heatmaps, meta, grid_centers, flip_xcoords=None, max_cubes_per_call: int = 16):
+        """All person proposals of a batch at once (inference): grid_centers (B,K,5) -> pred (B,K,J,3).
+
+        Replaces the reference's per-candidate loop (lib/models/multi_person_posenet.py:84-88, K
+        calls of this net with the full batch): ONE indexed unprojection launch over the valid
+        (b,k) pairs, V2V in chunks of ``max_cubes_per_call`` cubes, soft-argmax with in-kernel
+        grids.  Every proposal is independent in eval mode (BatchNorm uses running statistics), so
+        the result equals the loop's."""
+        B, K = grid_centers.shape[:2]
+        J = all_heatmaps[0].shape[1]
+        device = all_heatmaps[0].device
+        pred = torch.zeros(B, K, J, 3, device=device)
+        pairs = torch.nonzero(grid_centers[:, :, 3] >= 0)                 # (P,2), one host sync
+        P = int(pairs.shape[0])
+        if P == 0:
+            return pred
+        bi, ki = pairs[:, 0], pairs[:, 1]
+        centers = grid_centers[bi, ki, :3].contiguous()
+        flip = None if flip_xcoords is None else flip_xcoords
+        cubes, _ = self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, centers, self.cube_size,
+                                                flip_xcoords=flip, want_grids=False, pad_channels=True,
+                                                channels_last=self.channels_last, sample_of=bi)
+        outs = []
+        for s0 in range(0, P, max_cubes_per_call):
+            outs.append(_lib.soft_argmax_grid(self.v2v_net(cubes[s0:s0 + max_cubes_per_call]),
+                                              centers[s0:s0 + max_cubes_per_call], self.grid_size, self.cube_size,
+                                              self.soft_argmax_layer.beta))
+        pred[bi, ki] = torch.cat(outs, 0)
+        return pred
+
     def forward(self, all_heatmaps, meta, grid_centers, flip_xcoords=None):
         B, J = all_heatmaps[0].shape[:2]
         device = all_heatmaps[0].device

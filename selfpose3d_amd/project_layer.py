@@ -22,29 +22,56 @@ from . import _lib
 from .camera_pack import meta_cache_key, pack_cameras
 
 
+# Re-tiled heat-maps are shared by every projection of one forward pass (1 coarse + up to
+# MAX_PEOPLE_NUM fine calls read the same maps).  An entry is valid only while the very same
+# tensor OBJECTS are alive and unmodified (weak references + version counters): a freed tensor
+# whose address the allocator hands to the next batch can therefore never produce a false hit.
+_PACK_CACHE: "list[tuple]" = []
+
+
+def packed_heatmaps(hms: Sequence[torch.Tensor], jp: int) -> torch.Tensor:
+    import weakref
+    for refs, versions, cjp, packed in _PACK_CACHE:
+        if cjp == jp and len(refs) == len(hms) and all(r() is h and v == h._version for r, v, h in zip(refs, versions, hms)):
+            return packed
+    src = [h if (h.is_contiguous() and h.dtype == torch.float32) else h.contiguous().float() for h in hms]
+    packed = _lib.pack_heatmaps([x.detach() for x in src], jp=jp)
+    _PACK_CACHE.append((tuple(weakref.ref(h) for h in hms), tuple(h._version for h in hms), jp, packed))
+    while len(_PACK_CACHE) > 2:
+        _PACK_CACHE.pop(0)
+    return packed
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
 class _UnprojectFn(torch.autograd.Function):
     """autograd seam: gradient flows to the heat-maps only."""
 
     @staticmethod
     def forward(ctx, layer, cam, centers, valid, grid_size, cube_size, want_grids, mode, pad_channels, channels_last,
-                *heatmaps):
-        B, J, h, w = heatmaps[0].shape
+                sample_of, *heatmaps):
+        _, J, h, w = heatmaps[0].shape
+        B = int(centers.shape[0])                 # number of output cubes (== batch unless `sample_of` is given)
         hms = [x.detach() for x in heatmaps]
         hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
         if mode == "nhwc":
-            packed = _lib.pack_heatmaps(hms, jp=layer.jp_for(J))
+            packed = packed_heatmaps(heatmaps, layer.jp_for(J)) if layer.cache_packs else \
+                _lib.pack_heatmaps(hms, jp=layer.jp_for(J))
             jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
             # pad_channels: run the kernel over all jp channels - the padded ones are zero in `packed`,
             # so the extra output channels are exact zeros at no extra cost
             cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, B,
                                               jp if pad_channels else J, h, w, cube_size, grid_size, layer.img_size,
-                                              want_grids, channels_last=channels_last)
+                                              want_grids, channels_last=channels_last, sample_of=sample_of)
         else:
             cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
-                                              grid_size, layer.img_size, want_grids)
+                                              grid_size, layer.img_size, want_grids, sample_of=sample_of)
         ctx.layer = layer
         ctx.geom = (tuple(grid_size), tuple(cube_size))
+        ctx.sample_of = sample_of
         ctx.save_for_backward(cam, centers, valid, *hms)
         if grids is None:
             grids = torch.empty(0, device=cubes.device)
@@ -55,8 +82,9 @@ class _UnprojectFn(torch.autograd.Function):
     def backward(ctx, grad_cubes, _grad_grids):
         cam, centers, valid, *hms = ctx.saved_tensors
         grid_size, cube_size = ctx.geom
-        grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size)
-        return (None,) * 10 + tuple(grads)
+        grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size,
+                                   sample_of=ctx.sample_of)
+        return (None,) * 11 + tuple(grads)
 
 
 class ProjectLayer(nn.Module):
@@ -68,6 +96,7 @@ class ProjectLayer(nn.Module):
         self.img_size = [int(v) for v in cfg.NETWORK.IMAGE_SIZE]        # project_layer.py:19
         self.heatmap_size = [int(v) for v in cfg.NETWORK.HEATMAP_SIZE]  # project_layer.py:20
         self.mode = mode
+        self.cache_packs = True       # share the re-tiled heat-maps between the projections of one forward
         self._cam_key = None
         self._cam_dev = None
 
@@ -106,11 +135,13 @@ class ProjectLayer(nn.Module):
 
     # -- reference API -------------------------------------------------------------------
     def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True,
-                  pad_channels=False, channels_last=False):
+                  pad_channels=False, channels_last=False, sample_of=None):
         """Reference semantics (project_layer.py:42-102).  Extras for in-repo callers only:
         ``want_grids=False`` skips the (B,N,3) grid output, ``pad_channels`` returns
         ceil4(J) channels (zeros beyond J) and ``channels_last`` returns torch.channels_last_3d
-        strides - both let MIOpen's 3D convolutions run their fast paths without a copy."""
+        strides - both let MIOpen's 3D convolutions run their fast paths without a copy;
+        ``sample_of`` (int (P,)) with ``grid_center`` (P,5|3): P cubes, cube p read from sample
+        sample_of[p] (all person proposals of a batch in one launch)."""
         device = heatmaps[0].device
         if not heatmaps[0].is_cuda:
             raise _lib.Sp3dError("ProjectLayer: heat-maps must be on the GPU (no CPU fallback)")
@@ -119,7 +150,11 @@ class ProjectLayer(nn.Module):
             # the reference samples with cfg HEATMAP_SIZE (project_layer.py:50) whatever the tensor says
             raise _lib.Sp3dError(f"heat-map tensor is {w}x{h} but cfg.NETWORK.HEATMAP_SIZE is {self.heatmap_size}")
         cam = self.camera_table(meta, B, flip_xcoords, device)
-        centers, valid = self.centers_valid(grid_center, B, device)
+        if sample_of is not None:
+            sample_of = sample_of.to(device=device, dtype=torch.int32).contiguous()
+            centers, valid = self.centers_valid(grid_center, int(sample_of.shape[0]), device)
+        else:
+            centers, valid = self.centers_valid(grid_center, B, device)
         if isinstance(cube_size, int):
             cube_size = [cube_size] * 3
         if isinstance(grid_size, (int, float)):
@@ -133,7 +168,7 @@ class ProjectLayer(nn.Module):
             channels_last = False
         cubes, grids = _UnprojectFn.apply(self, cam, centers, valid, [float(v) for v in grid_size],
                                           [int(v) for v in cube_size], bool(want_grids), mode, bool(pad_channels),
-                                          bool(channels_last), *heatmaps)
+                                          bool(channels_last), sample_of, *heatmaps)
         return cubes, (grids if want_grids else None)
 
     def forward(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None):

@@ -343,3 +343,66 @@ def test_rootnet_channels_last_matches_default(dev):
         rc1, gc1 = net(hms, meta)
     assert float((rc0 - rc1).abs().max()) <= 2e-4
     assert torch.equal(gc0[:, :3, :3], gc1[:, :3, :3])
+
+
+def test_indexed_unprojection_and_batched_posenet(dev):
+    """all proposals of a batch in one launch == the reference's per-candidate loop"""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.pose_regression_net import PoseRegressionNet
+    from selfpose3d_amd.project_layer import ProjectLayer, clear_pack_cache
+    img, hm, J, B, V, K = [384, 288], [96, 72], 15, 3, 5, 4
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=img, NETWORK__HEATMAP_SIZE=hm, PICT_STRUCT__CUBE_SIZE=[16, 16, 16])
+    meta = syn.make_meta(B, V, img, rotations=[0.0, 10.0, -15.0], scale_mults=[1.0, 1.1, 0.9], ssv_style=True)
+    flip = torch.tensor([False, True, False])
+    hms, _ = syn.people_heatmaps(B, V, J, hm[1], hm[0], img, seed=77)
+    hms = [h.to(dev) for h in hms]
+    rng = np.random.default_rng(3)
+    gc = np.zeros((B, K, 5), np.float32)
+    gc[:, :, 0] = rng.uniform(-1500, 1500, (B, K)); gc[:, :, 1] = rng.uniform(-2000, 1000, (B, K))
+    gc[:, :, 2] = rng.uniform(700, 1100, (B, K)); gc[:, :, 3] = rng.integers(-1, 2, (B, K)); gc[:, :, 4] = 0.9
+    gc[0, 0, 3] = 0; gc[1, :, 3] = -1                                  # sample 1 has no valid proposal
+    gct = torch.from_numpy(gc).to(dev)
+    layer = ProjectLayer(cfg)
+    pairs = torch.nonzero(gct[:, :, 3] >= 0)
+    cubes_idx, grids_idx = layer.get_voxel(hms, meta, syn.FINE_GRID_SIZE, gct[pairs[:, 0], pairs[:, 1], :3].contiguous(),
+                                           [16, 16, 16], flip_xcoords=flip, sample_of=pairs[:, 0])
+    for p, (b, k) in enumerate(pairs.tolist()):
+        ref_c, ref_g = layer.get_voxel(hms, meta, syn.FINE_GRID_SIZE, gct[:, k], [16, 16, 16], flip_xcoords=flip)
+        assert torch.equal(cubes_idx[p], ref_c[b]) and torch.equal(grids_idx[p], ref_g[b])
+    # whole pose net: batched == loop
+    net = PoseRegressionNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=9, scale=0.05)
+    net.eval().to(dev)
+    with torch.no_grad():
+        loop = torch.stack([net(hms, meta, gct[:, k], flip_xcoords=flip) for k in range(K)], 1)
+        batched = net.forward_batched(hms, meta, gct, flip_xcoords=flip, max_cubes_per_call=3)
+    assert float((loop - batched).abs().max()) <= 0.5           # mm on +-2000 mm coords; MIOpen picks per-batch-size conv algos
+    assert torch.count_nonzero(batched[1]) == 0
+    # soft-argmax with in-kernel grids == with materialised grids
+    x = torch.rand(2, J, 16, 16, 16, device=dev)
+    cen = gct[pairs[:2, 0], pairs[:2, 1], :3].contiguous()
+    _, grids = layer.get_voxel(hms, meta, syn.FINE_GRID_SIZE, cen, [16, 16, 16], sample_of=pairs[:2, 0])
+    a = _lib.soft_argmax(x, grids, 100.0)
+    b2 = _lib.soft_argmax_grid(x, cen, syn.FINE_GRID_SIZE, [16, 16, 16], 100.0)
+    assert torch.equal(a, b2)
+    clear_pack_cache()
+
+
+def test_pack_cache_never_serves_stale_data(dev):
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer, _PACK_CACHE
+    case = gio.Case("unproj_coarse_small")
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+    layer = ProjectLayer(cfg)
+    hms = [h.to(dev) for h in case.hms]
+    a, _ = layer(hms, case.meta, case.grid_size, case.grid_center, case.cube)
+    n = len(_PACK_CACHE)
+    b, _ = layer(hms, case.meta, case.grid_size, case.grid_center, case.cube)     # hit
+    assert len(_PACK_CACHE) == n and torch.equal(a, b)
+    hms[0].mul_(0.5)                                                              # in-place edit: version bump
+    c, _ = layer(hms, case.meta, case.grid_size, case.grid_center, case.cube)
+    assert not torch.equal(a, c)
+    new = [h.clone() for h in hms]                                                # same values, new objects
+    d, _ = layer(new, case.meta, case.grid_size, case.grid_center, case.cube)
+    assert torch.equal(c, d)
