@@ -1,0 +1,123 @@
+"""Train / validate loops with the reference's call signatures (/root/reference/lib/core/function.py:
+219-349 ``train_3d``, :352-489 ``validate_3d``, :492-508 ``AverageMeter``) for one process per GPU.
+
+"Speed" keeps the reference's definition, views x frames / batch time (function.py:318), and is also
+reported per frame.  Debug image dumps and dataset metrics (need the real datasets) are not here.
+"""
+from __future__ import annotations
+
+import logging
+import time
+
+import torch
+
+logger = logging.getLogger(__name__)
+
+
+class AverageMeter:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = float(val)
+        self.sum += float(val) * n
+        self.count += n
+        self.avg = self.sum / max(1, self.count)
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def _to_device(x, dev):
+    if isinstance(x, torch.Tensor):
+        return x.to(dev, non_blocking=True)
+    if isinstance(x, (list, tuple)):
+        return [_to_device(v, dev) for v in x]
+    return x
+
+
+def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_dict=None, device=None, max_iters=None):
+    net = _unwrap(model)
+    device = device or next(net.parameters()).device
+    bt, dt, losses, l2d, l3d, lcord = (AverageMeter() for _ in range(6))
+    model.train()
+    if not config.NETWORK.TRAIN_BACKBONE and net.backbone is not None:
+        net.backbone.eval()                                                     # function.py:228-230
+    end = time.time()
+    for i, (inputs, targets_2d, weights_2d, targets_3d, meta, input_heatmap) in enumerate(loader):
+        if max_iters is not None and i >= max_iters:
+            break
+        dt.update(time.time() - end)
+        inputs = _to_device(inputs, device)
+        if config.NETWORK.TRAIN_ONLY_2D:
+            loss_2d, _ = model(views=inputs, meta=meta, targets_2d=targets_2d, weights_2d=weights_2d)
+            loss = loss_2d.mean()
+            l2d.update(loss.item())
+        else:
+            _, _, _, loss_2d, loss_3d, loss_cord = model(views=inputs, meta=meta, targets_2d=targets_2d,
+                                                         weights_2d=weights_2d, targets_3d=targets_3d[0])
+            loss_2d, loss_3d, loss_cord = loss_2d.mean(), loss_3d.mean(), loss_cord.mean()
+            l2d.update(loss_2d.item()); l3d.update(loss_3d.item()); lcord.update(loss_cord.item())
+            loss = loss_2d + loss_3d + loss_cord                                  # function.py:279
+        losses.update(loss.item())
+        optimizer.zero_grad(set_to_none=True)
+        if loss.requires_grad:
+            loss.backward()
+            optimizer.step()
+        bt.update(time.time() - end)
+        end = time.time()
+        if i % int(config.PRINT_FREQ) == 0:
+            V, B = len(inputs), inputs[0].size(0)
+            mem = torch.cuda.memory_allocated(device) / 2 ** 30 if device.type == "cuda" else 0.0
+            logger.info(f"Epoch: [{epoch}][{i}/{len(loader)}]\tTime: {bt.val:.3f}s ({bt.avg:.3f}s)\t"
+                        f"Speed: {V * B / max(bt.val, 1e-9):.1f} samples/s ({B / max(bt.val, 1e-9):.1f} frames/s)\t"
+                        f"Data: {dt.val:.3f}s ({dt.avg:.3f}s)\tLoss: {losses.val:.6f} ({losses.avg:.6f})\t"
+                        f"Loss_2d: {l2d.val:.7f} ({l2d.avg:.7f})\tLoss_3d: {l3d.val:.7f} ({l3d.avg:.7f})\t"
+                        f"Loss_cord: {lcord.val:.6f} ({lcord.avg:.6f})\tMemory {mem:.1f} GB")
+            if writer_dict and writer_dict.get("writer") is not None:
+                w, g = writer_dict["writer"], writer_dict["train_global_steps"]
+                w.add_scalar("train_loss_3d", l3d.val, g); w.add_scalar("train_loss_cord", lcord.val, g)
+                w.add_scalar("train_loss", losses.val, g)
+                writer_dict["train_global_steps"] = g + 1
+    return {"loss": losses.avg, "loss_2d": l2d.avg, "loss_3d": l3d.avg, "loss_cord": lcord.avg,
+            "batch_time": bt.avg}
+
+
+@torch.no_grad()
+def validate_3d(config, model, loader, epoch=0, output_dir=None, with_ssv=False, device=None, max_iters=None):
+    """-> precision proxy.  The reference scores AP/MPJPE with the dataset's evaluate() (needs the real
+    data); with synthetic frames we return the fraction of GT roots matched within 150 mm."""
+    net = _unwrap(model)
+    device = device or next(net.parameters()).device
+    model.eval()
+    bt = AverageMeter()
+    preds, matched, total = [], 0, 0
+    end = time.time()
+    for i, (inputs, targets_2d, weights_2d, targets_3d, meta, input_heatmap) in enumerate(loader):
+        if max_iters is not None and i >= max_iters:
+            break
+        inputs = _to_device(inputs, device)
+        pred, _, grid_centers, _, _, _ = model(views=inputs, meta=meta)
+        preds.append(pred.detach().cpu())
+        gc = grid_centers.detach().cpu()
+        roots, nper = meta[0]["roots_3d"].float(), meta[0]["num_person"]
+        for b in range(gc.shape[0]):
+            ok = gc[b, :, 3] >= 0
+            for p in range(int(nper[b])):
+                total += 1
+                if bool(ok.any()) and float((gc[b, ok, :3] - roots[b, p]).norm(dim=-1).min()) < 150.0:
+                    matched += 1
+        bt.update(time.time() - end)
+        end = time.time()
+        if i % int(config.PRINT_FREQ) == 0:
+            V, B = len(inputs), inputs[0].size(0)
+            logger.info(f"Test: [{i}/{len(loader)}]\tTime: {bt.val:.3f}s ({bt.avg:.3f}s)\t"
+                        f"Speed: {V * B / max(bt.val, 1e-9):.1f} samples/s ({B / max(bt.val, 1e-9):.1f} frames/s)")
+    recall = matched / max(1, total)
+    logger.info(f"root recall@150mm on synthetic frames: {recall:.4f} ({matched}/{total})")
+    return recall

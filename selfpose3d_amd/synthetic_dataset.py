@@ -1,0 +1,79 @@
+"""Synthetic Panoptic-shape dataset: the sample tuple and ``meta`` schema the reference's datasets
+emit (/root/reference/lib/dataset/JointsDataset.py:102-225, panoptic.py:221-233) without any real data
+(the CMU Panoptic files and OpenCV are not in the image).  Deterministic per (seed, index).
+
+item = (inputs[V] (3,H,W), target_heatmaps[V] (J,h,w), target_weights[V] (J,1), targets_3d[V] (X,Y,Z),
+        meta[V] dict, input_heatmaps[V] (J,h,w))  - default_collate adds the batch dim.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import synthetic as syn
+
+
+class SyntheticPanoptic(Dataset):
+    def __init__(self, cfg, num_frames: int = 32, seed: int = 0, max_people: int = 4, images: bool = True):
+        self.cfg = cfg
+        self.n = int(num_frames)
+        self.seed = int(seed)
+        self.V = int(cfg.DATASET.CAMERA_NUM)
+        self.J = int(cfg.NETWORK.NUM_JOINTS)
+        self.img = [int(v) for v in cfg.NETWORK.IMAGE_SIZE]
+        self.hm = [int(v) for v in cfg.NETWORK.HEATMAP_SIZE]
+        self.space_size = np.asarray(cfg.MULTI_PERSON.SPACE_SIZE, np.float64)
+        self.space_center = np.asarray(cfg.MULTI_PERSON.SPACE_CENTER, np.float64)
+        self.cube = [int(v) for v in cfg.MULTI_PERSON.INITIAL_CUBE_SIZE]
+        self.maxp = int(cfg.MULTI_PERSON.MAX_PEOPLE_NUM)
+        self.max_people = min(max_people, self.maxp)
+        self.root_id = int(cfg.DATASET.ROOTIDX) if not isinstance(cfg.DATASET.ROOTIDX, (list, tuple)) else 2
+        self.images = images
+        self.cams = syn.ring_cameras(self.V)
+        self.scale = syn.get_scale(syn.ORIG_IMAGE, self.img)
+
+    def __len__(self):
+        return self.n
+
+    def _target_3d(self, roots):
+        """max of 3D Gaussians (sigma 200 mm) at the roots (JointsDataset.generate_3d_target:304-341)"""
+        X, Y, Z = self.cube
+        gx = np.linspace(-self.space_size[0] / 2, self.space_size[0] / 2, X) + self.space_center[0]
+        gy = np.linspace(-self.space_size[1] / 2, self.space_size[1] / 2, Y) + self.space_center[1]
+        gz = np.linspace(-self.space_size[2] / 2, self.space_size[2] / 2, Z) + self.space_center[2]
+        t = np.zeros((X, Y, Z), np.float32)
+        for r in roots:
+            g = np.exp(-((gx[:, None, None] - r[0]) ** 2 + (gy[None, :, None] - r[1]) ** 2 +
+                         (gz[None, None, :] - r[2]) ** 2) / (2 * 200.0 ** 2))
+            t = np.maximum(t, g.astype(np.float32))
+        return np.clip(t, 0, 1)
+
+    def __getitem__(self, idx):
+        w, h = self.hm
+        hms, pts = syn.people_heatmaps(1, self.V, self.J, h, w, self.img, seed=self.seed * 100003 + idx,
+                                       sigma=float(self.cfg.NETWORK.SIGMA))
+        joints = pts[0][:self.max_people]                              # (P,J,3)
+        P = joints.shape[0]
+        j3d = np.zeros((self.maxp, self.J, 3)); j3d[:P] = joints
+        vis = np.zeros((self.maxp, self.J, 3)); vis[:P] = 1.0
+        roots = j3d[:, self.root_id]
+        t3d = torch.from_numpy(self._target_3d(roots[:P]))
+        rng = np.random.default_rng(self.seed * 7 + idx)
+        inputs, targets, weights, t3ds, metas, ihm = [], [], [], [], [], []
+        for v in range(self.V):
+            cam = self.cams[v]
+            img = torch.from_numpy(rng.standard_normal((3, self.img[1], self.img[0]), dtype=np.float32)) \
+                if self.images else torch.zeros(3, 1, 1)
+            inputs.append(img)
+            targets.append(hms[v][0])
+            weights.append(torch.ones(self.J, 1))
+            t3ds.append(t3d)
+            ihm.append(hms[v][0])
+            metas.append({
+                "image": f"synthetic/{idx:06d}_{v}", "num_person": P, "joints_3d": j3d, "joints_3d_vis": vis,
+                "roots_3d": roots, "center": np.array([syn.ORIG_IMAGE[0] / 2.0, syn.ORIG_IMAGE[1] / 2.0]),
+                "scale": self.scale.copy(), "rotation": 0,
+                "camera": {k: (np.asarray(val)) for k, val in cam.items()},
+            })
+        return inputs, targets, weights, t3ds, metas, ihm

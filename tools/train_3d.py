@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Training entry point, CLI of the reference's tools/train_3d.py (``--cfg X.yaml``), one process per
+GPU:   torchrun --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_3d.py --cfg X.yaml
+
+Replaces single-process nn.DataParallel (/root/reference/tools/train_3d.py:140) with
+DistributedDataParallel over RCCL (gradient all-reduce only); ``TRAIN.BATCH_SIZE`` stays the per-GPU
+batch.  Stage flags (TRAIN_BACKBONE / TRAIN_ONLY_ROOTNET / FREEZE_ROOTNET / USE_GT) select trainable
+parameters as in tools/train_3d.py:48-75; checkpoints keep the reference's names and keys.
+The real datasets are not in the image: frames come from SyntheticPanoptic (--frames).
+"""
+import argparse
+import logging
+import os
+
+import torch
+
+from _common import load_checkpoint, make_loader, save_checkpoint, setup
+from selfpose3d_amd import distributed as D
+from selfpose3d_amd.engine import train_3d, validate_3d
+from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+
+logger = logging.getLogger("train_3d")
+
+
+def select_trainable(model, cfg):
+    def req(mod, flag):
+        if mod is not None:
+            for p in mod.parameters():
+                p.requires_grad = flag
+    req(model.backbone, bool(cfg.NETWORK.TRAIN_BACKBONE))
+    if not cfg.NETWORK.TRAIN_ONLY_2D:
+        if not cfg.NETWORK.TRAIN_ONLY_ROOTNET:
+            req(model.pose_net, True)
+        else:
+            req(model.pose_net, False)
+        if not cfg.NETWORK.USE_GT:
+            req(model.root_net, not cfg.NETWORK.FREEZE_ROOTNET)
+    return [p for p in model.parameters() if p.requires_grad]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", required=True)
+    ap.add_argument("--frames", type=int, default=32, help="synthetic frames per epoch (global)")
+    ap.add_argument("--max-iters", type=int, default=None)
+    args, _ = ap.parse_known_args()
+    cfg, rank, world, device, out = setup(args.cfg, "train")
+    train_loader = make_loader(cfg, args.frames, int(cfg.TRAIN.BATCH_SIZE), rank, world, seed=1,
+                               shuffle=bool(cfg.TRAIN.SHUFFLE))
+    test_loader = make_loader(cfg, max(world, args.frames // 4), int(cfg.TEST.BATCH_SIZE), rank, world, seed=2,
+                              shuffle=False)
+    model = get_multi_person_pose_net(cfg, is_train=True).to(device)
+    if device.type == "cuda":
+        model.use_channels_last(True)
+    params = select_trainable(model, cfg)
+    optimizer = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
+    start, best, last = (load_checkpoint(model, optimizer, out) if cfg.TRAIN.RESUME else (int(cfg.TRAIN.BEGIN_EPOCH), 0.0, -1))
+    ddp = D.wrap_ddp(model, device, find_unused=True)
+    sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, list(cfg.TRAIN.LR_STEP), float(cfg.TRAIN.LR_FACTOR),
+                                                 last_epoch=last)
+    for epoch in range(start, int(cfg.TRAIN.END_EPOCH)):
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        stats = train_3d(cfg, ddp, optimizer, train_loader, epoch, out, None, device, args.max_iters)
+        sched.step()
+        prec = None if cfg.NETWORK.TRAIN_ONLY_2D else validate_3d(cfg, ddp, test_loader, epoch, out, device=device,
+                                                                  max_iters=args.max_iters)
+        is_best = prec is not None and prec > best
+        best = max(best, prec or 0.0)
+        if rank == 0:
+            logger.info(f"epoch {epoch}: {stats}  precision {prec}")
+            save_checkpoint({"epoch": epoch + 1, "state_dict": model.state_dict(), "precision": best,
+                             "optimizer": optimizer.state_dict()}, is_best, out)
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(out, "final_state.pth.tar"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
