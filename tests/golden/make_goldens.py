@@ -260,6 +260,70 @@ def main():
                         root_keys=np.array(sorted(rootnet.state_dict().keys())),
                         pose_keys=np.array(sorted(posenet.state_dict().keys())))
     print("rootnet grid_centers[0,:3]", grid_centers[0, :3].numpy())
+
+    # ------------------------------------------------------------------ SSL root net: synthetic-root branch (f3/f4)
+    # train_rootnet (cuboid_proposal_net_soft.py:151-241) draws its roots internally; pin the RNG calls so
+    # the roots are known, switch the additive noise off, and capture the rendered heat-maps it hands to
+    # the project layer.  B = 1 (the reference only supports that).
+    from models.cuboid_proposal_net_soft import CuboidProposalNetSoft
+    img, hm = (960, 512), (240, 128)
+    cfgs = make_cfg(img, hm, syn.SPACE_SIZE, syn.SPACE_CENTER, syn.INITIAL_CUBE_SIZE, syn.FINE_GRID_SIZE, (16, 16, 16), 15,
+                    roothm=True)
+    cfgs.NETWORK.ROOTNET_TRAIN_SYNTH = True
+    cfgs.NETWORK.ROOTNET_SYN_RANGE = [[2500.0, -2000.0], [1500.0, -1500.0], [250.0, -300.0]]
+    cfgs.TRAIN = AD(BATCH_SIZE=1)
+    soft = CuboidProposalNetSoft(cfgs)
+    V = 5
+    meta = syn.make_meta(1, V, img, ssv_style=True)
+    for m in meta:
+        cam = m["camera"]
+        cam["f"] = torch.stack([cam["fx"], cam["fy"]], -1).reshape(1, 2, 1)
+        cam["c"] = torch.stack([cam["cx"], cam["cy"]], -1).reshape(1, 2, 1)
+    from utils.transforms import get_affine_transform as gat
+    tr = gat(meta[0]["center"][0].numpy(), meta[0]["scale"][0].numpy(), 0, list(img))
+    meta[0]["trans"] = torch.from_numpy(np.asarray(tr, np.float32))[None]
+    R = 3
+    u = np.random.default_rng(61).random((1, R, 2)).astype(np.float32)
+    uz = np.float32(0.37)
+    zn = np.random.default_rng(62).standard_normal((1, R, 1)).astype(np.float32)
+    calls = {"rand": 0}
+    o_randint, o_rand, o_randn_like = torch.randint, torch.rand, torch.randn_like
+
+    def f_randint(*a, **k):
+        return torch.tensor([R])
+
+    def f_rand(*shape, **k):
+        calls["rand"] += 1
+        if calls["rand"] == 1:
+            return torch.from_numpy(u[..., 0:1].copy())
+        if calls["rand"] == 2:
+            return torch.from_numpy(u[..., 1:2].copy())
+        return torch.full((1, 1, 1), float(uz))
+
+    def f_randn_like(t, **k):
+        if tuple(t.shape) == (1, R, 1):
+            return torch.from_numpy(zn.copy())
+        return torch.zeros_like(t)
+
+    captured = {}
+
+    class RecProject(torch.nn.Module):
+        def forward(self, hms, *a, **k):
+            captured["hms"] = [h.clone() for h in hms]
+            return torch.zeros(1, 1, *syn.INITIAL_CUBE_SIZE), None
+
+    soft.project_layer = RecProject()
+    soft.v2v_net = torch.nn.Identity()
+    torch.randint, torch.rand, torch.randn_like = f_randint, f_rand, f_randn_like
+    try:
+        _, target_cubes = soft.train_rootnet(1, meta, None)
+    finally:
+        torch.randint, torch.rand, torch.randn_like = o_randint, o_rand, o_randn_like
+    np.savez_compressed(os.path.join(HERE, "rootnet_soft_synth.npz"), u=u, uz=uz, zn=zn, R=R,
+                        target=target_cubes.numpy(), hms=np.stack([h.numpy() for h in captured["hms"]]),
+                        trans=meta[0]["trans"].numpy(), lo=np.array([soft.min_x, soft.min_y, soft.min_z]),
+                        hi=np.array([soft.max_x, soft.max_y, soft.max_z]))
+    print("rootnet_soft target", target_cubes.shape, float(target_cubes.max()), "hms", captured["hms"][0].shape)
     print("posenet pred[0][0,:2]", preds[0][0, :2])
 
 

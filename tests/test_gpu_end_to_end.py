@@ -58,3 +58,34 @@ def test_cli_entry_points(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "root recall" in r.stderr
+
+
+def test_rootnet_soft_forward_and_synthetic_training_branch():
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    from selfpose3d_amd.cuboid_proposal_net_soft import CuboidProposalNetSoft
+    dev = torch.device("cuda:0")
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[384, 288], NETWORK__HEATMAP_SIZE=[96, 72],
+                      NETWORK__ROOTNET_ROOTHM=True, NETWORK__ROOTNET_TRAIN_SYNTH=True,
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[24, 24, 8])
+    B, V, J = 2, 5, 15
+    meta = syn.make_meta(B, V, (384, 288))
+    hms, _ = syn.people_heatmaps(B, V, J, 72, 96, (384, 288), seed=11)
+    hms = [h.to(dev) for h in hms]
+    soft = CuboidProposalNetSoft(cfg)
+    syn.fill_parameters_deterministic(soft, seed=5, scale=0.05)
+    soft.to(dev).eval()
+    plain = CuboidProposalNet(cfg)
+    plain.load_state_dict(soft.state_dict())
+    plain.to(dev).eval()
+    with torch.no_grad():
+        rc_s, a, b, gc_s = soft(hms, meta)
+        rc_p, gc_p = plain(hms, meta)
+    assert a is None and b is None and torch.equal(rc_s, rc_p) and torch.equal(gc_s, gc_p)
+    soft.train()
+    rc, syn_cubes, target, gc = soft(hms, meta)
+    assert syn_cubes.shape == target.shape == (B, 24, 24, 8)
+    loss = torch.nn.functional.mse_loss(syn_cubes, target)
+    loss.backward()
+    assert soft.v2v_net.output_layer.weight.grad is not None
