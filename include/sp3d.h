@@ -144,6 +144,17 @@ int sp3d_soft_argmax(const float *x, const float *grids, float *out, int Bv, int
 int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
                           float *out, int Bv, int J, float beta, void *stream);
 
+/*
+ * Fused inference epilogue for the V2V conv stack (BatchNorm folded into the conv weights by the
+ * caller): in place on y (batch, C, inner) [planar] or (batch, inner, C) [channels_last],
+ *   mode 0: y += shift[c]   1: relu(y + shift[c])   2: relu(y + shift[c] + residual)
+ *   mode 3: relu(y + shift[c]) + residual
+ * replacing the separate bias / BatchNorm3d / ReLU / add kernels of lib/models/v2v_net.py:13-17,
+ * 26-45, 60-69, 100-108.  Needs C % 4 == 0 (channels_last) or inner % 4 == 0 (planar).
+ */
+int sp3d_channel_shift_act(float *y, const float *shift, const float *residual, int mode, int64_t batch, int C,
+                           int64_t inner, int channels_last, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid",
+    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act",
 ]
 
 _lib = None
@@ -67,6 +67,8 @@ def load():
     lib.sp3d_unproject_bwd_indexed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_soft_argmax_grid.restype = I
     lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
+    lib.sp3d_channel_shift_act.restype = I
+    lib.sp3d_channel_shift_act.argtypes = [P, P, P, I, C.c_int64, I, C.c_int64, I, V]
     if hasattr(lib, "sp3d_unproject_fwd_variant"):
         lib.sp3d_unproject_fwd_variant.restype = I
         lib.sp3d_unproject_fwd_variant.argtypes = [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, V]
@@ -220,3 +222,24 @@ def soft_argmax_grid(x: torch.Tensor, centers: torch.Tensor, grid_size, cube_siz
     check(lib.sp3d_soft_argmax_grid(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(), P, J,
                                     float(beta), _stream(x.device)), "sp3d_soft_argmax_grid")
     return out
+
+
+def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual: Optional[torch.Tensor] = None):
+    """in place on a 5-D activation (B,C,D,H,W) that is dense in NCDHW or channels_last_3d order:
+    mode 0 y+=shift[c]; 1 relu(y+shift); 2 relu(y+shift+residual); 3 relu(y+shift)+residual"""
+    lib = load()
+    _require_cuda(y, "y")
+    B, Cc = int(y.shape[0]), int(y.shape[1])
+    inner = int(y.numel() // max(1, B * Cc))
+    if y.is_contiguous():
+        cl = 0
+    elif y.is_contiguous(memory_format=torch.channels_last_3d):
+        cl = 1
+    else:
+        raise Sp3dError("channel_shift_act_: activation must be dense (NCDHW or channels_last_3d)")
+    if residual is not None:
+        if residual.shape != y.shape or residual.stride() != y.stride():
+            residual = residual.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
+    check(lib.sp3d_channel_shift_act(y.data_ptr(), shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                     int(mode), B, Cc, inner, cl, _stream(y.device)), "sp3d_channel_shift_act")
+    return y

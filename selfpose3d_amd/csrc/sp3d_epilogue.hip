@@ -1,0 +1,73 @@
+// sp3d_epilogue.hip - fused per-channel shift (+ residual) (+ ReLU) epilogue for the V2V conv stack
+// in inference.  The reference runs Conv3d -> BatchNorm3d -> ReLU (and `relu(res + skip)`,
+// `upsample + skip`) as separate library kernels (/root/reference/lib/models/v2v_net.py:13-17,
+// 26-45, 60-69, 100-108).  With BatchNorm folded into the conv weights on the host
+// (selfpose3d_amd/v2v_net.py::_FoldedV2V) what is left per layer is ONE memory-bound pass:
+//     mode 0: y = y + shift[c]
+//     mode 1: y = relu(y + shift[c])
+//     mode 2: y = relu(y + shift[c] + r)          (residual block output)
+//     mode 3: y = relu(y + shift[c]) + r          (up-sampling block + skip connection)
+// in place, dwordx4 per lane, channels-last (c = element % C) or planar (c = (element / inner) % C).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sp3d.h"
+
+namespace sp3d {
+
+template <int MODE, bool CL>
+__global__ __launch_bounds__(256) void channel_shift_act_kernel(float *__restrict__ y, const float *__restrict__ shift,
+                                                               const float *__restrict__ res, int64_t n4, int C,
+                                                               int64_t inner)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4 *>(y)[i];
+        float s0, s1, s2, s3;
+        if (CL) {   // C % 4 == 0: the four elements are four consecutive channels
+            const int c = (int)((i * 4) % C);
+            const float4 s = *reinterpret_cast<const float4 *>(shift + c);
+            s0 = s.x; s1 = s.y; s2 = s.z; s3 = s.w;
+        } else {    // inner % 4 == 0: the four elements share one channel
+            const int c = (int)(((i * 4) / inner) % C);
+            s0 = s1 = s2 = s3 = shift[c];
+        }
+        v.x += s0; v.y += s1; v.z += s2; v.w += s3;
+        if (MODE == 2) {
+            const float4 r = reinterpret_cast<const float4 *>(res)[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (MODE >= 1) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+        if (MODE == 3) {
+            const float4 r = reinterpret_cast<const float4 *>(res)[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        reinterpret_cast<float4 *>(y)[i] = v;
+    }
+}
+
+} // namespace sp3d
+
+using namespace sp3d;
+
+extern "C" int sp3d_channel_shift_act(float *y, const float *shift, const float *residual, int mode, int64_t batch,
+                                      int C, int64_t inner, int channels_last, void *stream)
+{
+    if (batch <= 0 || C <= 0 || inner <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
+    if (!y || !shift || ((mode >= 2) && !residual)) return SP3D_ENULL;
+    if (channels_last ? (C & 3) : (inner & 3)) return SP3D_EUNSUPPORTED;
+    const int64_t n4 = batch * C * inner / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+#define SP3D_EPI(M, CL) hipLaunchKernelGGL((channel_shift_act_kernel<M, CL>), dim3(blocks), dim3(256), 0, s, y, shift, residual, n4, C, inner)
+    if (channels_last) {
+        switch (mode) { case 0: SP3D_EPI(0, true); break; case 1: SP3D_EPI(1, true); break; case 2: SP3D_EPI(2, true); break; default: SP3D_EPI(3, true); }
+    } else {
+        switch (mode) { case 0: SP3D_EPI(0, false); break; case 1: SP3D_EPI(1, false); break; case 2: SP3D_EPI(2, false); break; default: SP3D_EPI(3, false); }
+    }
+#undef SP3D_EPI
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}

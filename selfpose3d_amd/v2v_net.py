@@ -99,12 +99,102 @@ class _EncDec(nn.Module):
         return x
 
 
+class _FoldedV2V:
+    """Inference execution plan of a V2VNet: every BatchNorm3d (running statistics) is folded into the
+    preceding (transposed) conv's weights, so a layer is one MIOpen conv (no bias) + ONE fused
+    in-place epilogue (sp3d_channel_shift_act: shift [+ residual] [+ ReLU]) instead of conv + bias +
+    BatchNorm + ReLU (+ add) kernels.  Same math as v2v_net.py:10-110 up to fp32 rounding of the
+    folded weights.  Rebuilt whenever a parameter / buffer version, device or memory format changes."""
+
+    def __init__(self, net: "V2VNet"):
+        self.net = net
+        self.key = None
+        self.t = {}
+
+    @staticmethod
+    def _key(net):
+        ps = list(net.parameters()) + list(net.buffers())
+        w = net.output_layer.weight
+        return (sum(p._version for p in ps), str(w.device), w.is_contiguous(memory_format=torch.channels_last_3d),
+                tuple(id(p) for p in ps[:4]))
+
+    @staticmethod
+    def _fold(conv, bn, transposed=False):
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shape = (1, -1, 1, 1, 1) if transposed else (-1, 1, 1, 1, 1)
+        w = conv.weight * s.view(shape)
+        fmt = torch.channels_last_3d if conv.weight.is_contiguous(memory_format=torch.channels_last_3d) and \
+            not conv.weight.is_contiguous() else torch.contiguous_format
+        b = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        return w.contiguous(memory_format=fmt), ((b - bn.running_mean) * s + bn.bias).contiguous()
+
+    def _build(self):
+        n, t = self.net, {}
+        t["front"] = self._fold(n.front_layers[0].block[0], n.front_layers[0].block[1])
+        def res(name, blk):
+            w1, s1 = self._fold(blk.res_branch[0], blk.res_branch[1])
+            w2, s2 = self._fold(blk.res_branch[3], blk.res_branch[4])
+            if len(blk.skip_con) > 0:
+                ws, ss = self._fold(blk.skip_con[0], blk.skip_con[1])
+                t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws)
+            else:
+                t[name] = (w1, s1, w2, s2, None)
+        res("front_res", n.front_layers[1])
+        ed = n.encoder_decoder
+        for name in ("encoder_res1", "encoder_res2", "mid_res", "decoder_res2", "decoder_res1", "skip_res1", "skip_res2"):
+            res(name, getattr(ed, name))
+        for name in ("decoder_upsample2", "decoder_upsample1"):
+            blk = getattr(ed, name).block
+            t[name] = self._fold(blk[0], blk[1], transposed=True)
+        self.t = t
+
+    def _res(self, x, name):
+        from . import _lib
+        w1, s1, w2, s2, ws = self.t[name]
+        h = _lib.channel_shift_act_(F.conv3d(x, w1, None, 1, 1), s1, 1)
+        u = F.conv3d(h, w2, None, 1, 1)
+        r = x if ws is None else F.conv3d(x, ws, None, 1, 0)
+        return _lib.channel_shift_act_(u, s2, 2, r)
+
+    @torch.no_grad()
+    def run(self, x):
+        from . import _lib
+        key = self._key(self.net)
+        if key != self.key:
+            self._build()
+            self.key = key
+        w0, s0 = self.t["front"]
+        cin = w0.shape[1]
+        have = x.shape[1]
+        target = have if have > cin else ((cin + 3) // 4 * 4 if cin >= 3 else cin)
+        if target != cin:
+            w0 = F.pad(w0, (0, 0, 0, 0, 0, 0, 0, target - cin))
+        if have < target:
+            x = F.pad(x, (0, 0, 0, 0, 0, 0, 0, target - have))
+        x = _lib.channel_shift_act_(F.conv3d(x, w0, None, 1, 3), s0, 1)
+        x = self._res(x, "front_res")
+        skip1 = self._res(x, "skip_res1")
+        x = self._res(F.max_pool3d(x, 2, 2), "encoder_res1")
+        skip2 = self._res(x, "skip_res2")
+        x = self._res(F.max_pool3d(x, 2, 2), "encoder_res2")
+        x = self._res(self._res(x, "mid_res"), "decoder_res2")
+        wT, sT = self.t["decoder_upsample2"]
+        x = _lib.channel_shift_act_(F.conv_transpose3d(x, wT, None, 2), sT, 3, skip2)
+        x = self._res(x, "decoder_res1")
+        wT, sT = self.t["decoder_upsample1"]
+        x = _lib.channel_shift_act_(F.conv_transpose3d(x, wT, None, 2), sT, 3, skip1)
+        o = self.net.output_layer
+        return F.conv3d(x, o.weight, o.bias)
+
+
 class V2VNet(nn.Module):
     def __init__(self, input_channels: int, output_channels: int):
         super().__init__()
         self.front_layers = nn.Sequential(ConvBnRelu3d(input_channels, 16, 7), Residual3d(16, 32))
         self.encoder_decoder = _EncDec()
         self.output_layer = nn.Conv3d(32, output_channels, 1, 1, 0)
+        self.fused_inference = True      # eval + no_grad + GPU: BatchNorm-folded plan with fused epilogues
+        self._plan = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -115,4 +205,9 @@ class V2VNet(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x):
+        if self.fused_inference and not self.training and not torch.is_grad_enabled() and x.is_cuda \
+                and x.dtype == torch.float32 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[4] % 4 == 0:
+            if self._plan is None:
+                self._plan = _FoldedV2V(self)
+            return self._plan.run(x)
         return self.output_layer(self.encoder_decoder(self.front_layers(x)))

@@ -406,3 +406,50 @@ def test_pack_cache_never_serves_stale_data(dev):
     new = [h.clone() for h in hms]                                                # same values, new objects
     d, _ = layer(new, case.meta, case.grid_size, case.grid_center, case.cube)
     assert torch.equal(c, d)
+
+
+@pytest.mark.parametrize("cl", [False, True])
+def test_v2v_fused_inference_plan_matches_module(dev, cl):
+    """BatchNorm-folded convs + fused HIP epilogues == the plain module (fp32 rounding only)"""
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.v2v_net import V2VNet
+    for cin, cout, shape in ((15, 1, (2, 15, 16, 16, 8)), (15, 15, (1, 16, 16, 16, 16)), (1, 1, (2, 1, 8, 8, 8))):
+        net = V2VNet(cin, cout)
+        syn.fill_parameters_deterministic(net, seed=21, scale=0.05)
+        net.eval().to(dev)
+        x = torch.rand(shape, device=dev)
+        if cl:
+            net.to(memory_format=torch.channels_last_3d)
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        with torch.no_grad():
+            net.fused_inference = False
+            ref = net(x)
+            net.fused_inference = True
+            got = net(x)
+            assert net._plan is not None and net._plan.key is not None
+            assert float((ref - got).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+            # parameters change -> the folded plan is rebuilt
+            net.output_layer.bias.add_(1.0)
+            net.front_layers[0].block[1].running_mean.add_(0.1)
+            net.fused_inference = False
+            ref2 = net(x)
+            net.fused_inference = True
+            got2 = net(x)
+            assert float((ref2 - got2).abs().max()) <= 1e-4 * max(1.0, float(ref2.abs().max()))
+            assert float((ref2 - ref).abs().max()) > 1e-3
+
+
+def test_channel_shift_act_modes(dev):
+    from selfpose3d_amd import _lib
+    for cl in (False, True):
+        y = torch.randn(2, 8, 4, 4, 4, device=dev)
+        r = torch.randn_like(y)
+        if cl:
+            y = y.contiguous(memory_format=torch.channels_last_3d)
+            r = r.contiguous(memory_format=torch.channels_last_3d)
+        s = torch.randn(8, device=dev)
+        sv = s.view(1, -1, 1, 1, 1)
+        exp = [y + sv, torch.relu(y + sv), torch.relu(y + sv + r), torch.relu(y + sv) + r]
+        for mode in range(4):
+            got = _lib.channel_shift_act_(y.clone(memory_format=torch.preserve_format), s, mode, r if mode >= 2 else None)
+            assert torch.equal(got, exp[mode]), (cl, mode)
