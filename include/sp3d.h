@@ -63,7 +63,12 @@ enum {
     SP3D_LAYOUT_NHWC = 1,    /* view c: (B, h, w, Jp) fp32, Jp%4==0, channels >= J are ignored padding */
     /* OR-ed into hm_layout: write `cubes` channels-last, (B, X, Y, Z, J) with J%4==0 (NHWC input
      * only) - the layout MIOpen's 3D convolutions consume without an internal transpose. */
-    SP3D_OUT_CHANNELS_LAST = 0x100
+    SP3D_OUT_CHANNELS_LAST = 0x100,
+    /* OR-ed into hm_layout (NHWC, Jp == 16): the packed heat-maps / the cubes are stored as bf16
+     * (BASELINE configs[4] "mixed bf16": storage only - projection, interpolation and view fusion
+     * stay fp32; cubes are rounded to nearest-even on the final store). */
+    SP3D_HM_BF16 = 0x200,
+    SP3D_OUT_BF16 = 0x400
 };
 
 int sp3d_abi_version(void);
@@ -76,6 +81,10 @@ const char *sp3d_error_string(int code);
  */
 int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V, int J, int Jp, int h, int w,
                        void *stream);
+/* same with explicit storage types: in_bf16 / out_bf16 = 1 when the planar inputs / the packed output
+ * hold bf16 instead of fp32 (bf16 needs Jp == 16) */
+int sp3d_pack_heatmaps_ex(const void *const *hm_views, void *packed, int in_bf16, int out_bf16, int B, int V, int J,
+                          int Jp, int h, int w, void *stream);
 
 /*
  * ProjectLayer.get_voxel forward (project_layer.py:42-102; math: DESIGN.md §3).

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libsp3d.so")
 LAYOUT_PLANAR = 0
 LAYOUT_NHWC = 1
 OUT_CHANNELS_LAST = 0x100
+HM_BF16 = 0x200
+OUT_BF16 = 0x400
 MAX_VIEWS = 16
 MAX_TOPK = 32
 ABI_VERSION = 1
@@ -25,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act",
+    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
 ]
 
 _lib = None
@@ -51,6 +53,8 @@ def load():
     lib.sp3d_error_string.argtypes = [I]
     lib.sp3d_pack_heatmaps.restype = I
     lib.sp3d_pack_heatmaps.argtypes = [P, P, I, I, I, I, I, I, V]
+    lib.sp3d_pack_heatmaps_ex.restype = I
+    lib.sp3d_pack_heatmaps_ex.argtypes = [P, P, I, I, I, I, I, I, I, I, V]
     lib.sp3d_unproject_fwd.restype = I
     lib.sp3d_unproject_fwd.argtypes = [P, I, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd.restype = I
@@ -104,17 +108,21 @@ def _f3(vals):
     return (C.c_float * 3)(float(vals[0]), float(vals[1]), float(vals[2]))
 
 
-def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """list[V] of (B,J,h,w) fp32 contiguous -> (V,B,h,w,jp) channels-last, padded channels zero."""
+def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch.Tensor] = None,
+                  out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """list[V] of (B,J,h,w) fp32|bf16 contiguous -> (V,B,h,w,jp) channels-last (fp32|bf16), padded channels zero."""
     lib = load()
     h0 = hms[0]
     _require_cuda(h0, "heatmaps")
     B, J, h, w = h0.shape
     V = len(hms)
-    hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
+    in_dt = torch.bfloat16 if h0.dtype == torch.bfloat16 else torch.float32
+    hms = [x if (x.is_contiguous() and x.dtype == in_dt) else x.contiguous().to(in_dt) for x in hms]
+    out_dtype = out.dtype if out is not None else (out_dtype or torch.float32)
     if out is None:
-        out = torch.empty((V, B, h, w, jp), dtype=torch.float32, device=h0.device)
-    check(lib.sp3d_pack_heatmaps(_ptr_array(hms), out.data_ptr(), B, V, J, jp, h, w, _stream(h0.device)),
+        out = torch.empty((V, B, h, w, jp), dtype=out_dtype, device=h0.device)
+    check(lib.sp3d_pack_heatmaps_ex(_ptr_array(hms), out.data_ptr(), int(in_dt == torch.bfloat16),
+                                    int(out_dtype == torch.bfloat16), B, V, J, jp, h, w, _stream(h0.device)),
           "sp3d_pack_heatmaps")
     return out
 
@@ -122,7 +130,7 @@ def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch
 def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
                   want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False,
-                  sample_of: Optional[torch.Tensor] = None):
+                  sample_of: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32):
     """-> (cubes (B,J,X,Y,Z), grids (B,N,3) | None).  With ``channels_last`` the cubes tensor has
     torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only).
     ``sample_of`` (int32, (B,)): output cube p reads heat-map/camera row sample_of[p] (B = #cubes)."""
@@ -132,13 +140,15 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
     X, Y, Z = (int(c) for c in cube_size)
     V = len(views)
     if channels_last:
-        cubes = torch.empty((B, X, Y, Z, J), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
+        cubes = torch.empty((B, X, Y, Z, J), dtype=out_dtype, device=dev).permute(0, 4, 1, 2, 3)
     else:
-        cubes = torch.empty((B, J, X, Y, Z), dtype=torch.float32, device=dev)
+        cubes = torch.empty((B, J, X, Y, Z), dtype=out_dtype, device=dev)
+    flags = (OUT_CHANNELS_LAST if channels_last else 0) | (HM_BF16 if views[0].dtype == torch.bfloat16 else 0) | \
+        (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
     grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
     gs = _f3(grid_size)
     if variant is None:
-        rc = lib.sp3d_unproject_fwd_indexed(_ptr_array(views), layout | (OUT_CHANNELS_LAST if channels_last else 0),
+        rc = lib.sp3d_unproject_fwd_indexed(_ptr_array(views), layout | flags,
                                             jp, cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                             centers.data_ptr(), valid.data_ptr(), cubes.data_ptr(),
                                             grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
@@ -162,7 +172,8 @@ def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: 
     P = int(grad_cubes.shape[0])
     X, Y, Z = (int(c) for c in cube_size)
     V = len(hms)
-    grad_cubes = grad_cubes[:, :J].contiguous().float()
+    hms = [x if x.dtype == torch.float32 else x.float() for x in hms]
+    grad_cubes = grad_cubes[:, :J].float().contiguous()
     grads = torch.zeros((V, B, J, h, w), dtype=torch.float32, device=dev)
     gviews = [grads[c] for c in range(V)]
     rc = lib.sp3d_unproject_bwd_indexed(_ptr_array(hms), cam.data_ptr(),

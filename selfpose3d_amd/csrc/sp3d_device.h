@@ -218,6 +218,40 @@ __device__ __forceinline__ float fuse_rcp(float acc, float den, float rden)
     return __builtin_amdgcn_fmed3f(o, 0.0f, 1.0f);   // med3(NaN,0,1) = 0: the NaN->0 rule of project_layer.py:98
 }
 
+// ---- storage types: fp32 or bf16 (math is always fp32) -----------------------------------------
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)       // round to nearest even (values here are finite)
+{
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Store4;
+template <> struct Store4<float> {
+    __device__ __forceinline__ static float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    __device__ __forceinline__ static void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    __device__ __forceinline__ static void store1(float *p, float v) { *p = v; }
+};
+template <> struct Store4<bf16_t> {
+    __device__ __forceinline__ static float4 load(const bf16_t *p)
+    {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    __device__ __forceinline__ static void store(bf16_t *p, float4 v)
+    {
+        uint2 r;
+        r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = r;
+    }
+    __device__ __forceinline__ static void store1(bf16_t *p, float v) { p->v = f32_to_bf16(v); }
+};
+
 // blockIdx -> logical tile so that each XCD (observed: block b runs on XCD b % 8) walks a
 // CONTIGUOUS range of (sample, voxel-tile) work and its 4 MiB L2 sees one sample's
 // heat-maps instead of all of them.  Speed only: any placement gives the same results.

@@ -102,31 +102,35 @@ __global__ __launch_bounds__(TILE) void unproject_planar_kernel(Views hm, const 
 // ------------------------------------------------------------------------------------------
 constexpr int PSTR = 260; // LDS row stride (floats): rows 16-B aligned, <=2-way write conflicts
 
-template <int JP>
-__global__ __launch_bounds__(256) void pack_nhwc_kernel(Views hm, float *__restrict__ packed, int B, int J, int HW)
+template <int JP, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(256) void pack_nhwc_kernel(Views hm, float *__restrict__ packed_, int B, int J, int HW)
 {
     __shared__ float tile[JP][PSTR];
     const int tid = threadIdx.x;
     const int p0 = blockIdx.x * 256;
     const int b = blockIdx.y, v = blockIdx.z;
-    const float *src = hm.p[v] + (size_t)b * J * HW;
+    const TI *src = reinterpret_cast<const TI *>(hm.p[v]) + (size_t)b * J * HW;
+    TO *packed = reinterpret_cast<TO *>(packed_);
     const int p = p0 + tid;
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
         float val = 0.0f;
-        if (j < J && p < HW) val = src[(size_t)j * HW + p];
+        if (j < J && p < HW) {
+            if constexpr (sizeof(TI) == 2) val = bf16_to_f32(reinterpret_cast<const uint16_t *>(src)[(size_t)j * HW + p]);
+            else val = reinterpret_cast<const float *>(src)[(size_t)j * HW + p];
+        }
         tile[j][tid] = val;
     }
     __syncthreads();
     constexpr int NQ = JP / 4;
-    float *dst = packed + (((size_t)v * B + b) * HW + p0) * JP;
+    TO *dst = packed + (((size_t)v * B + b) * HW + p0) * JP;
     for (int e = tid; e < 256 * NQ; e += 256) {
         const int px = e / NQ, q = e - px * NQ;
         if (p0 + px < HW) {
             float4 o;
             o.x = tile[4 * q + 0][px]; o.y = tile[4 * q + 1][px];
             o.z = tile[4 * q + 2][px]; o.w = tile[4 * q + 3][px];
-            *reinterpret_cast<float4 *>(dst + (size_t)px * JP + 4 * q) = o;
+            Store4<TO>::store(dst + (size_t)px * JP + 4 * q, o);
         }
     }
 }
@@ -341,7 +345,8 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 }
 
 // NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
-template <int JP, bool XCD, int NW, bool OUTCL>
+// TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
+template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float>
 __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
                                                              const float *__restrict__ centers,
                                                              const uint8_t *__restrict__ valid,
@@ -363,13 +368,13 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     const int n0 = (lt - b * tiles_per_sample) * (64 * NW) + wave * 64;   // first voxel of this wave
     if (n0 >= g.N) return;
     const int nvox = min(64, g.N - n0);
-    float *cb = cubes + (size_t)b * g.J * g.N;
+    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
     float *ws = smem + wave * WLDS;
     int *wsi = reinterpret_cast<int *>(ws);
 
     if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
         for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) cb[OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)] = 0.0f;
+            if (lane < nvox) Store4<TO>::store1(cb + (OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)), 0.0f);
         if (grids && lane < nvox) {
             float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
             gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
@@ -424,15 +429,15 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const float *vb = hm.p[c] + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
             const int rb = (c & 1) * 320 + g16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float *p = vb + wsi[rb + 16 * i];
-                t00[i] = *reinterpret_cast<const float4 *>(p);
-                t10[i] = *reinterpret_cast<const float4 *>(p + JP);
-                t01[i] = *reinterpret_cast<const float4 *>(p + rowf);
-                t11[i] = *reinterpret_cast<const float4 *>(p + rowf + JP);
+                const TI *p = vb + wsi[rb + 16 * i];
+                t00[i] = Store4<TI>::load(p);
+                t10[i] = Store4<TI>::load(p + JP);
+                t01[i] = Store4<TI>::load(p + rowf);
+                t11[i] = Store4<TI>::load(p + rowf + JP);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
                 float4 o;
                 o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
                 o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                *reinterpret_cast<float4 *>(cb + (size_t)(n0 + nn) * g.J + 4 * q) = o;
+                Store4<TO>::store(cb + (size_t)(n0 + nn) * g.J + 4 * q, o);
             }
         } else if (qact) {
 #pragma unroll
@@ -484,11 +489,11 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         for (int j = lane >> 4; j < g.J; j += 4) {
             const int u = lane & 15;
             const float4 o = *reinterpret_cast<const float4 *>(&ws[j * WOSTR + 4 * u]);
-            *reinterpret_cast<float4 *>(cb + (size_t)j * g.N + n0 + 4 * u) = o;
+            Store4<TO>::store(cb + (size_t)j * g.N + n0 + 4 * u, o);
         }
     } else {
         for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) cb[(size_t)j * g.N + n0 + lane] = ws[j * WOSTR + lane];
+            if (lane < nvox) Store4<TO>::store1(cb + (size_t)j * g.N + n0 + lane, ws[j * WOSTR + lane]);
     }
 }
 
@@ -646,7 +651,7 @@ static int launch_status()
 
 template <int JP>
 static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
-                          float *grids, const Geom &g, int variant, bool out_cl, hipStream_t s)
+                          float *grids, const Geom &g, int variant, bool out_cl, int io, hipStream_t s)
 {
     const int tiles = (g.N + TILE - 1) / TILE;
     const int total = tiles * g.B;
@@ -660,6 +665,31 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         dim3 pgrid(xcd ? ((ptotal + 7) / 8) * 8 : ptotal), pblock(64 * nw);
 #define SP3D_PIPE(XCD_, NW_, CL_) \
     hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
+#define SP3D_PIPE_T(XCD_, CL_, TI_, TO_) \
+    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, 1, CL_, TI_, TO_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
+        if (io != 0) {   // bf16 storage variants: JP == 16, one wave per workgroup only
+            if constexpr (JP == 16) {
+                if (nw != 1) return SP3D_EUNSUPPORTED;
+                const int sel = (io & 3) * 4 + (out_cl ? 2 : 0) + (xcd ? 1 : 0);
+                switch (sel) {
+                case 4: SP3D_PIPE_T(false, false, bf16_t, float); break;
+                case 5: SP3D_PIPE_T(true, false, bf16_t, float); break;
+                case 6: SP3D_PIPE_T(false, true, bf16_t, float); break;
+                case 7: SP3D_PIPE_T(true, true, bf16_t, float); break;
+                case 8: SP3D_PIPE_T(false, false, float, bf16_t); break;
+                case 9: SP3D_PIPE_T(true, false, float, bf16_t); break;
+                case 10: SP3D_PIPE_T(false, true, float, bf16_t); break;
+                case 11: SP3D_PIPE_T(true, true, float, bf16_t); break;
+                case 12: SP3D_PIPE_T(false, false, bf16_t, bf16_t); break;
+                case 13: SP3D_PIPE_T(true, false, bf16_t, bf16_t); break;
+                case 14: SP3D_PIPE_T(false, true, bf16_t, bf16_t); break;
+                default: SP3D_PIPE_T(true, true, bf16_t, bf16_t); break;
+                }
+                return SP3D_OK;
+            } else {
+                return SP3D_EUNSUPPORTED;
+            }
+        }
         if (out_cl) {
             if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, true); else SP3D_PIPE(false, 1, true); }
             else { if (xcd) SP3D_PIPE(true, 4, true); else SP3D_PIPE(false, 4, true); }
@@ -667,10 +697,11 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
             if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, false); else SP3D_PIPE(false, 1, false); }
             else { if (xcd) SP3D_PIPE(true, 4, false); else SP3D_PIPE(false, 4, false); }
         }
+#undef SP3D_PIPE_T
 #undef SP3D_PIPE
         return SP3D_OK;
     }
-    if (out_cl) return SP3D_EUNSUPPORTED;
+    if (out_cl || io) return SP3D_EUNSUPPORTED;
 #define SP3D_LAUNCH(XCD_, U_) \
     hipLaunchKernelGGL((unproject_nhwc_kernel<JP, XCD_, U_>), grid, block, lds, s, v, cam, centers, valid, cubes, grids, g, tiles, total)
     switch (variant & 3) {
@@ -682,18 +713,21 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
     return SP3D_OK;
 }
 
+// io: bit 0 = packed heat-maps are bf16, bit 1 = cubes are bf16
 static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *centers, const uint8_t *valid,
-                       float *cubes, float *grids, const Geom &g, int variant, bool out_cl, hipStream_t s)
+                       float *cubes, float *grids, const Geom &g, int variant, bool out_cl, int io, hipStream_t s)
 {
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
     if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;    // the clamped 2x2 block needs a 2x2 image
+    if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
+    if (io) variant |= 16;
     int rc;
     switch (Jp) {
-    case 4: rc = launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
-    case 8: rc = launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
-    case 12: rc = launch_nhwc_jp<12>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
-    case 16: rc = launch_nhwc_jp<16>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, s); break;
+    case 4: rc = launch_nhwc_jp<4>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, io, s); break;
+    case 8: rc = launch_nhwc_jp<8>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, io, s); break;
+    case 12: rc = launch_nhwc_jp<12>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, io, s); break;
+    case 16: rc = launch_nhwc_jp<16>(v, cam, centers, valid, cubes, grids, g, variant, out_cl, io, s); break;
     default: return SP3D_EUNSUPPORTED;
     }
     return rc ? rc : launch_status();
@@ -717,26 +751,40 @@ extern "C" const char *sp3d_error_string(int code)
     }
 }
 
-extern "C" int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V, int J, int Jp, int h,
-                                  int w, void *stream)
+extern "C" int sp3d_pack_heatmaps_ex(const void *const *hm_views, void *packed, int in_bf16, int out_bf16, int B, int V,
+                                     int J, int Jp, int h, int w, void *stream)
 {
     if (B <= 0 || V <= 0 || J <= 0 || h <= 0 || w <= 0 || V > SP3D_MAX_VIEWS) return SP3D_EINVAL;
     if (!packed) return SP3D_ENULL;
     if (Jp < J || (Jp & 3)) return SP3D_EUNSUPPORTED;
     Views v;
-    int rc = load_views(v, hm_views, V);
+    int rc = load_views(v, reinterpret_cast<const float *const *>(hm_views), V);
     if (rc) return rc;
     const int HW = h * w;
     dim3 grid((HW + 255) / 256, B, V), block(256);
     hipStream_t s = (hipStream_t)stream;
-    switch (Jp) {
-    case 4: hipLaunchKernelGGL(pack_nhwc_kernel<4>, grid, block, 0, s, v, packed, B, J, HW); break;
-    case 8: hipLaunchKernelGGL(pack_nhwc_kernel<8>, grid, block, 0, s, v, packed, B, J, HW); break;
-    case 12: hipLaunchKernelGGL(pack_nhwc_kernel<12>, grid, block, 0, s, v, packed, B, J, HW); break;
-    case 16: hipLaunchKernelGGL(pack_nhwc_kernel<16>, grid, block, 0, s, v, packed, B, J, HW); break;
-    default: return SP3D_EUNSUPPORTED;
+    float *pk = reinterpret_cast<float *>(packed);
+    if (!in_bf16 && !out_bf16) {
+        switch (Jp) {
+        case 4: hipLaunchKernelGGL(pack_nhwc_kernel<4>, grid, block, 0, s, v, pk, B, J, HW); break;
+        case 8: hipLaunchKernelGGL(pack_nhwc_kernel<8>, grid, block, 0, s, v, pk, B, J, HW); break;
+        case 12: hipLaunchKernelGGL(pack_nhwc_kernel<12>, grid, block, 0, s, v, pk, B, J, HW); break;
+        case 16: hipLaunchKernelGGL(pack_nhwc_kernel<16>, grid, block, 0, s, v, pk, B, J, HW); break;
+        default: return SP3D_EUNSUPPORTED;
+        }
+    } else {
+        if (Jp != 16) return SP3D_EUNSUPPORTED;
+        if (in_bf16 && out_bf16) hipLaunchKernelGGL((pack_nhwc_kernel<16, bf16_t, bf16_t>), grid, block, 0, s, v, pk, B, J, HW);
+        else if (in_bf16) hipLaunchKernelGGL((pack_nhwc_kernel<16, bf16_t, float>), grid, block, 0, s, v, pk, B, J, HW);
+        else hipLaunchKernelGGL((pack_nhwc_kernel<16, float, bf16_t>), grid, block, 0, s, v, pk, B, J, HW);
     }
     return launch_status();
+}
+
+extern "C" int sp3d_pack_heatmaps(const float *const *hm_views, float *packed, int B, int V, int J, int Jp, int h,
+                                  int w, void *stream)
+{
+    return sp3d_pack_heatmaps_ex(reinterpret_cast<const void *const *>(hm_views), packed, 0, 0, B, V, J, Jp, h, w, stream);
 }
 
 extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
@@ -755,9 +803,10 @@ extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_l
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g.N + TILE - 1) / TILE;
     const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
+    const int io = ((hm_layout & SP3D_HM_BF16) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0);
     hm_layout &= 0xff;
     if (hm_layout == SP3D_LAYOUT_PLANAR) {
-        if (out_cl) return SP3D_EUNSUPPORTED;
+        if (out_cl || io) return SP3D_EUNSUPPORTED;
         dim3 grid(tiles, P), block(TILE);
         if (J == 1)
             hipLaunchKernelGGL(unproject_planar_kernel<1>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
@@ -767,7 +816,7 @@ extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_l
             hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         return launch_status();
     }
-    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(P), out_cl, s);
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(P), out_cl, io, s);
     return SP3D_EINVAL;
 }
 
@@ -833,5 +882,5 @@ extern "C" int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, 
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
-    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & 0xff, (variant & 0x100) != 0, (hipStream_t)stream);
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & 0xff, (variant & 0x100) != 0, 0, (hipStream_t)stream);
 }

@@ -29,14 +29,14 @@ from .camera_pack import meta_cache_key, pack_cameras
 _PACK_CACHE: "list[tuple]" = []
 
 
-def packed_heatmaps(hms: Sequence[torch.Tensor], jp: int) -> torch.Tensor:
+def packed_heatmaps(hms: Sequence[torch.Tensor], jp: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     import weakref
     for refs, versions, cjp, packed in _PACK_CACHE:
-        if cjp == jp and len(refs) == len(hms) and all(r() is h and v == h._version for r, v, h in zip(refs, versions, hms)):
+        if cjp == (jp, dtype) and len(refs) == len(hms) and \
+                all(r() is h and v == h._version for r, v, h in zip(refs, versions, hms)):
             return packed
-    src = [h if (h.is_contiguous() and h.dtype == torch.float32) else h.contiguous().float() for h in hms]
-    packed = _lib.pack_heatmaps([x.detach() for x in src], jp=jp)
-    _PACK_CACHE.append((tuple(weakref.ref(h) for h in hms), tuple(h._version for h in hms), jp, packed))
+    packed = _lib.pack_heatmaps([x.detach() for x in hms], jp=jp, out_dtype=dtype)
+    _PACK_CACHE.append((tuple(weakref.ref(h) for h in hms), tuple(h._version for h in hms), (jp, dtype), packed))
     while len(_PACK_CACHE) > 2:
         _PACK_CACHE.pop(0)
     return packed
@@ -55,17 +55,20 @@ class _UnprojectFn(torch.autograd.Function):
         _, J, h, w = heatmaps[0].shape
         B = int(centers.shape[0])                 # number of output cubes (== batch unless `sample_of` is given)
         hms = [x.detach() for x in heatmaps]
-        hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
+        io = layer.io_dtype
+        if io == torch.float32:
+            hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
         if mode == "nhwc":
-            packed = packed_heatmaps(heatmaps, layer.jp_for(J)) if layer.cache_packs else \
-                _lib.pack_heatmaps(hms, jp=layer.jp_for(J))
+            packed = packed_heatmaps(heatmaps, layer.jp_for(J), io) if layer.cache_packs else \
+                _lib.pack_heatmaps(hms, jp=layer.jp_for(J), out_dtype=io)
             jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
             # pad_channels: run the kernel over all jp channels - the padded ones are zero in `packed`,
             # so the extra output channels are exact zeros at no extra cost
             cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, B,
                                               jp if pad_channels else J, h, w, cube_size, grid_size, layer.img_size,
-                                              want_grids, channels_last=channels_last, sample_of=sample_of)
+                                              want_grids, channels_last=channels_last, sample_of=sample_of,
+                                              out_dtype=io)
         else:
             cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
                                               grid_size, layer.img_size, want_grids, sample_of=sample_of)
@@ -91,8 +94,11 @@ class ProjectLayer(nn.Module):
     """See module docstring.  ``mode``: "nhwc" (re-tile + fast kernel, J <= 16), "planar"
     (direct kernel on the reference layout) or "auto"."""
 
-    def __init__(self, cfg, mode: str = "auto"):
+    def __init__(self, cfg, mode: str = "auto", io_dtype: torch.dtype = torch.float32):
         super().__init__()
+        # storage type of the re-tiled heat-maps and of the cubes: fp32 (reference) or bf16 ("mixed bf16",
+        # BASELINE configs[4]); projection / interpolation / fusion arithmetic is fp32 either way
+        self.io_dtype = io_dtype
         self.img_size = [int(v) for v in cfg.NETWORK.IMAGE_SIZE]        # project_layer.py:19
         self.heatmap_size = [int(v) for v in cfg.NETWORK.HEATMAP_SIZE]  # project_layer.py:20
         self.mode = mode
@@ -162,6 +168,8 @@ class ProjectLayer(nn.Module):
         mode = self.mode
         if mode == "auto":
             mode = "nhwc" if (J <= 16 and w >= 2 and h >= 2) else "planar"
+        if self.io_dtype != torch.float32 and (mode != "nhwc" or self.jp_for(J) != 16):
+            raise _lib.Sp3dError("bf16 storage needs the NHWC path with 13..16 joints")
         if mode != "nhwc":
             pad_channels = channels_last = False
         if channels_last and not pad_channels and (J & 3):

@@ -453,3 +453,40 @@ def test_channel_shift_act_modes(dev):
         for mode in range(4):
             got = _lib.channel_shift_act_(y.clone(memory_format=torch.preserve_format), s, mode, r if mode >= 2 else None)
             assert torch.equal(got, exp[mode]), (cl, mode)
+
+
+@pytest.mark.parametrize("V", [3, 4])
+def test_bf16_storage_config(dev, V):
+    """BASELINE configs[4]: 3-4 views, fine 64^3 per-person voxels, heat-maps / cubes stored as bf16, math fp32.
+    Parity definition: oracle run on the bf16-rounded heat-maps, its fp32 result rounded to bf16 (RNE)."""
+    from oracle import oracle
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.camera_pack import pack_cameras
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    B, J, img, hm, cube = 2, 15, (384, 288), (96, 72), (64, 64, 64)
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=list(img), NETWORK__HEATMAP_SIZE=list(hm))
+    meta = syn.make_meta(B, V, img)
+    hms32 = syn.random_heatmaps(B, V, J, hm[1], hm[0], seed=50 + V)
+    hms16 = [h.to(torch.bfloat16) for h in hms32]
+    gc = torch.tensor([[300.0, -800.0, 900.0, 0.0, 0.9], [-700.0, 100.0, 1000.0, 1.0, 0.8]])
+    cam = pack_cameras(meta, B, img)
+    ref, ref_g = oracle.unproject_fwd([h.float().numpy() for h in hms16], cam, gc[:, :3].numpy(), np.ones(B, np.uint8),
+                                      syn.FINE_GRID_SIZE, cube, img)
+    ref16 = torch.from_numpy(ref).to(torch.bfloat16)
+    layer = ProjectLayer(cfg, io_dtype=torch.bfloat16)
+    for src in (hms16, hms32):                    # bf16 producer, or fp32 producer rounded inside the pack kernel
+        cubes, grids = layer([h.to(dev) for h in src], meta, syn.FINE_GRID_SIZE, gc.to(dev), list(cube))
+        assert cubes.dtype == torch.bfloat16 and grids.dtype == torch.float32
+        assert torch.equal(cubes.cpu(), ref16)
+        assert np.array_equal(grids.cpu().numpy(), ref_g)
+    # bf16 in, fp32 out and channels-last padded bf16 out
+    packed = _lib.pack_heatmaps([h.to(dev) for h in hms16], jp=16, out_dtype=torch.bfloat16)
+    camd, cen, val = torch.from_numpy(cam).to(dev), gc[:, :3].contiguous().to(dev), torch.ones(B, dtype=torch.uint8, device=dev)
+    c32, _ = _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, camd, cen, val, B, J, hm[1], hm[0],
+                                cube, syn.FINE_GRID_SIZE, img, False)
+    assert torch.equal(c32.cpu(), torch.from_numpy(ref))
+    ccl, _ = _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, camd, cen, val, B, 16, hm[1], hm[0],
+                                cube, syn.FINE_GRID_SIZE, img, False, channels_last=True, out_dtype=torch.bfloat16)
+    assert ccl.is_contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(ccl[:, :J].cpu(), ref16) and torch.count_nonzero(ccl[:, J:]) == 0

@@ -68,6 +68,13 @@ def main():
         for v in variants:
             fns[f"nhwc_v{v}"] = (lambda v=v: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J,
                                                                 h, w, cube, gs, img, False, variant=v))
+        packed16 = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
+        views16 = [packed16[c] for c in range(V)]
+        fns["nhwc_bf16_in"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
+                                                         cube, gs, img, False)
+        fns["nhwc_bf16_io"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
+                                                         cube, gs, img, False, out_dtype=torch.bfloat16)
+        fns["pack_bf16"] = lambda: _lib.pack_heatmaps(hms, jp=16, out=packed16)
         times = {k: [] for k in fns}
         for k, fn in fns.items():
             timed(fn, 5)
@@ -79,7 +86,7 @@ def main():
         for k, ts in times.items():
             med, mn = float(np.median(ts)), float(np.min(ts))
             report[name][k] = {"median_us": round(med, 2), "min_us": round(mn, 2),
-                               "alg_GBps_at_median": round(alg / med / 1e3, 1) if k != "pack" else None}
+                               "alg_GBps_at_median": round(alg / med / 1e3, 1) if not k.startswith("pack") else None}
     print(json.dumps(report, indent=1))
 
 
