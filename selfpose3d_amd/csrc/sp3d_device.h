@@ -252,13 +252,42 @@ template <> struct Store4<bf16_t> {
     __device__ __forceinline__ static void store1(bf16_t *p, float v) { p->v = f32_to_bf16(v); }
 };
 
-// blockIdx -> logical tile so that each XCD (observed: block b runs on XCD b % 8) walks a
-// CONTIGUOUS range of (sample, voxel-tile) work and its 4 MiB L2 sees one sample's
-// heat-maps instead of all of them.  Speed only: any placement gives the same results.
-__device__ __forceinline__ int xcd_remap(int bid, int total)
+// blockIdx -> (sample, tile) with XCD affinity AND balance.  Observed placement: block `bid` runs on
+// XCD bid % 8 (speed only - any placement gives the same results).  Each XCD has its own 4 MiB L2, so
+// all tiles of one sample should run on as few XCDs as possible (its heat-maps are then fetched into
+// those L2s only); but voxel tiles differ a lot in cost (camera visibility), so the tiles of a sample
+// are dealt round-robin to the XCDs that serve it instead of in contiguous ranges:
+//   B <= 8, 8 % B == 0 : sample b is served by the 8/B XCDs {b*8/B ...}, tile t by XCD (t % (8/B))
+//   B  > 8, B % 8 == 0 : XCD x serves samples x, x+8, ... whole
+//   otherwise          : plain interleave (tile-major order), still correct, less affinity
+// returns false if this block has no work.  grid size: xcd_grid_blocks().
+__host__ __device__ __forceinline__ int xcd_slots_per_xcd(int B, int tiles)
 {
-    const int per = (total + 7) >> 3;
-    return (bid & 7) * per + (bid >> 3);
+    if (B <= 8 && (8 % B) == 0) { const int xps = 8 / B; return (tiles + xps - 1) / xps; }
+    if (B > 8 && (B % 8) == 0) return (B / 8) * tiles;
+    return (B * tiles + 7) / 8;
+}
+__host__ __device__ __forceinline__ int xcd_grid_blocks(int B, int tiles) { return 8 * xcd_slots_per_xcd(B, tiles); }
+
+__device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int &b, int &tile)
+{
+    const int x = bid & 7, slot = bid >> 3;
+    if (B <= 8 && (8 % B) == 0) {
+        const int xps = 8 / B;
+        b = x / xps;
+        tile = slot * xps + (x - b * xps);
+        return tile < tiles;
+    }
+    if (B > 8 && (B % 8) == 0) {
+        const int j = slot / tiles;
+        b = x + 8 * j;
+        tile = slot - j * tiles;
+        return b < B;
+    }
+    const int lt = slot * 8 + x;          // plain order
+    b = lt / tiles;
+    tile = lt - b * tiles;
+    return b < B;
 }
 
 } // namespace sp3d

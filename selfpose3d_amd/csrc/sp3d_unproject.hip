@@ -156,14 +156,16 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
     float *sIy = sIx + g.V * TILE;                        // [V][TILE]
     uint32_t *sMask = reinterpret_cast<uint32_t *>(sIy + g.V * TILE); // [TILE]
 
-    int lt = blockIdx.x;
+    int b, tile;
     if (XCD) {
-        lt = xcd_remap(blockIdx.x, total_tiles);
-        if (lt >= total_tiles) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+    } else {
+        b = blockIdx.x / tiles_per_sample;
+        tile = blockIdx.x - b * tiles_per_sample;
     }
-    const int b = lt / tiles_per_sample;
+    (void)total_tiles;
     const int bs = g.sample_of ? g.sample_of[b] : b;
-    const int n0 = (lt - b * tiles_per_sample) * TILE;
+    const int n0 = tile * TILE;
     const int tid = threadIdx.x;
     const int nvox = min(TILE, g.N - n0);
     float *cb = cubes + (size_t)b * g.J * g.N;
@@ -346,8 +348,8 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 
 // NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
 // TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
-template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
+template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float, int U = 4>
+__global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
                                                              const float *__restrict__ centers,
                                                              const uint8_t *__restrict__ valid,
                                                              float *__restrict__ cubes, float *__restrict__ grids,
@@ -357,15 +359,17 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
     __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
 
-    int lt = blockIdx.x;
+    int b, tile;
     if (XCD) {
-        lt = xcd_remap(blockIdx.x, total_tiles);
-        if (lt >= total_tiles) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+    } else {
+        b = blockIdx.x / tiles_per_sample;
+        tile = blockIdx.x - b * tiles_per_sample;
     }
-    const int b = lt / tiles_per_sample;
+    (void)total_tiles;
     const int bs = g.sample_of ? g.sample_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = (lt - b * tiles_per_sample) * (64 * NW) + wave * 64;   // first voxel of this wave
+    const int n0 = tile * (64 * NW) + wave * 64;                          // first voxel of this wave
     if (n0 >= g.N) return;
     const int nvox = min(64, g.N - n0);
     TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
@@ -424,36 +428,45 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     bool have = P1(0);
 #pragma unroll 1
     for (int c = 0; c < g.V; ++c) {
-        float4 t00[4], t10[4], t01[4], t11[4];
         const bool cur = have;
+        const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+        const int rb = (c & 1) * 320 + g16;
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
-            const int rb = (c & 1) * 320 + g16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const TI *p = vb + wsi[rb + 16 * i];
-                t00[i] = Store4<TI>::load(p);
-                t10[i] = Store4<TI>::load(p + JP);
-                t01[i] = Store4<TI>::load(p + rowf);
-                t11[i] = Store4<TI>::load(p + rowf + JP);
-            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
-        __builtin_amdgcn_sched_barrier(0);
-        if (cur) {
-            const int rb = (c & 1) * 320 + g16;
+        // the 4 voxel slots of this lane group are gathered U at a time (4*U dwordx4 loads in flight);
+        // P1(c+1) is scheduled between the first group's loads and its FMAs
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                float v;
-                v = t00[i].x * w00; v = fmaf(t10[i].x, w10, v); v = fmaf(t01[i].x, w01, v); v = fmaf(t11[i].x, w11, v); acc[i][0] = acc[i][0] + v;
-                v = t00[i].y * w00; v = fmaf(t10[i].y, w10, v); v = fmaf(t01[i].y, w01, v); v = fmaf(t11[i].y, w11, v); acc[i][1] = acc[i][1] + v;
-                v = t00[i].z * w00; v = fmaf(t10[i].z, w10, v); v = fmaf(t01[i].z, w01, v); v = fmaf(t11[i].z, w11, v); acc[i][2] = acc[i][2] + v;
-                v = t00[i].w * w00; v = fmaf(t10[i].w, w10, v); v = fmaf(t01[i].w, w01, v); v = fmaf(t11[i].w, w11, v); acc[i][3] = acc[i][3] + v;
+        for (int gi = 0; gi < 4 / U; ++gi) {
+            float4 t00[U], t10[U], t01[U], t11[U];
+            if (cur) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
+                    t00[k] = Store4<TI>::load(p);
+                    t10[k] = Store4<TI>::load(p + JP);
+                    t01[k] = Store4<TI>::load(p + rowf);
+                    t11[k] = Store4<TI>::load(p + rowf + JP);
+                }
+            }
+            if (gi == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cur) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int i = gi * U + k;
+                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
+                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
+                    float v;
+                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
+                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
+                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
+                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
+                }
             }
         }
     }
@@ -647,7 +660,7 @@ static int launch_status()
 // variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable the XCD-aware tile map;
 // bit 3: per-wave software-pipelined kernel (unproject_pipe_kernel); bit 4: one wave per workgroup
 // default: pipelined kernel; XCD-aware tile map only when several samples share the chip
-#define SP3D_DEFAULT_VARIANT(B) ((B) >= 2 ? 24 : 28)
+#define SP3D_DEFAULT_VARIANT(B) (24)
 
 template <int JP>
 static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
@@ -657,12 +670,12 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
     const int total = tiles * g.B;
     const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
     const bool xcd = !(variant & 4);
-    dim3 grid(xcd ? ((total + 7) / 8) * 8 : total), block(TILE);
+    dim3 grid(xcd ? xcd_grid_blocks(g.B, tiles) : total), block(TILE);
     if (variant & 8) {
         const int nw = (variant & 16) ? 1 : 4;
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
         const int ptotal = ptiles * g.B;
-        dim3 pgrid(xcd ? ((ptotal + 7) / 8) * 8 : ptotal), pblock(64 * nw);
+        dim3 pgrid(xcd ? xcd_grid_blocks(g.B, ptiles) : ptotal), pblock(64 * nw);
 #define SP3D_PIPE(XCD_, NW_, CL_) \
     hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
 #define SP3D_PIPE_T(XCD_, CL_, TI_, TO_) \
@@ -689,6 +702,11 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
             } else {
                 return SP3D_EUNSUPPORTED;
             }
+        }
+        if ((variant & 32) && nw == 1 && !out_cl) {   // A/B: two voxel slots in flight, more waves per SIMD
+            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 2>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 2>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            return SP3D_OK;
         }
         if (out_cl) {
             if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, true); else SP3D_PIPE(false, 1, true); }
