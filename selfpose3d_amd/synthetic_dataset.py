@@ -36,6 +36,15 @@ class SyntheticPanoptic(Dataset):
     def __len__(self):
         return self.n
 
+    def _image(self, idx, v):
+        """N(0,1) camera image from a small pool (content is irrelevant to the geometry; avoids 7 M normal
+        draws per frame on the host)"""
+        if not hasattr(self, "_pool"):
+            rng = np.random.default_rng(self.seed + 12345)
+            self._pool = [torch.from_numpy(rng.standard_normal((3, self.img[1], self.img[0]), dtype=np.float32))
+                          for _ in range(4)]
+        return self._pool[(idx * self.V + v) % len(self._pool)]
+
     def _target_3d(self, roots):
         """max of 3D Gaussians (sigma 200 mm) at the roots (JointsDataset.generate_3d_target:304-341)"""
         X, Y, Z = self.cube
@@ -43,28 +52,46 @@ class SyntheticPanoptic(Dataset):
         gy = np.linspace(-self.space_size[1] / 2, self.space_size[1] / 2, Y) + self.space_center[1]
         gz = np.linspace(-self.space_size[2] / 2, self.space_size[2] / 2, Z) + self.space_center[2]
         t = np.zeros((X, Y, Z), np.float32)
-        for r in roots:
-            g = np.exp(-((gx[:, None, None] - r[0]) ** 2 + (gy[None, :, None] - r[1]) ** 2 +
-                         (gz[None, None, :] - r[2]) ** 2) / (2 * 200.0 ** 2))
-            t = np.maximum(t, g.astype(np.float32))
+        for r in roots:                                   # separable: exp on the three 1-D profiles
+            ex = np.exp(-((gx - r[0]) ** 2) / (2 * 200.0 ** 2))
+            ey = np.exp(-((gy - r[1]) ** 2) / (2 * 200.0 ** 2))
+            ez = np.exp(-((gz - r[2]) ** 2) / (2 * 200.0 ** 2))
+            t = np.maximum(t, (ex[:, None, None] * ey[None, :, None] * ez[None, None, :]).astype(np.float32))
         return np.clip(t, 0, 1)
+
+    def _render(self, joints):
+        """separable Gaussian rendering (exp on 1-D profiles, outer product, max over people): list[V] (J,h,w)"""
+        w, h = self.hm
+        sigma = float(self.cfg.NETWORK.SIGMA)
+        s = self.scale.astype(np.float64) * 200.0
+        a = self.img[0] / s[0] if s[0] >= s[1] else self.img[1] / s[1]
+        t = np.array([self.img[0] / 2.0, self.img[1] / 2.0]) - a * np.array(syn.ORIG_IMAGE) / 2.0
+        xs, ys = np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64)
+        P = joints.shape[0]
+        out = []
+        for cam in self.cams:
+            px = syn._project_f64(joints.reshape(-1, 3), cam).reshape(P, self.J, 2)
+            qq = (px * a + t) * np.array([w, h]) / np.array(self.img, dtype=np.float64)
+            gx = np.exp(-((xs[None, None, :] - qq[..., 0:1]) ** 2) / (2 * sigma ** 2))      # (P,J,w)
+            gy = np.exp(-((ys[None, None, :] - qq[..., 1:2]) ** 2) / (2 * sigma ** 2))      # (P,J,h)
+            hm = (gy[..., :, None] * gx[..., None, :]).max(axis=0)                            # (J,h,w)
+            out.append(torch.from_numpy(np.clip(hm, 0, 1).astype(np.float32)))
+        return out
 
     def __getitem__(self, idx):
         w, h = self.hm
-        hms, pts = syn.people_heatmaps(1, self.V, self.J, h, w, self.img, seed=self.seed * 100003 + idx,
-                                       sigma=float(self.cfg.NETWORK.SIGMA))
+        pts = syn.people_points(1, self.J, self.seed * 100003 + idx)
         joints = pts[0][:self.max_people]                              # (P,J,3)
+        hms = [x[None] for x in self._render(joints)]
         P = joints.shape[0]
         j3d = np.zeros((self.maxp, self.J, 3)); j3d[:P] = joints
         vis = np.zeros((self.maxp, self.J, 3)); vis[:P] = 1.0
         roots = j3d[:, self.root_id]
         t3d = torch.from_numpy(self._target_3d(roots[:P]))
-        rng = np.random.default_rng(self.seed * 7 + idx)
         inputs, targets, weights, t3ds, metas, ihm = [], [], [], [], [], []
         for v in range(self.V):
             cam = self.cams[v]
-            img = torch.from_numpy(rng.standard_normal((3, self.img[1], self.img[0]), dtype=np.float32)) \
-                if self.images else torch.zeros(3, 1, 1)
+            img = self._image(idx, v) if self.images else torch.zeros(3, 1, 1)
             inputs.append(img)
             targets.append(hms[v][0])
             weights.append(torch.ones(self.J, 1))

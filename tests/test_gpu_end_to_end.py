@@ -48,7 +48,7 @@ def test_cli_entry_points(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_3d.py"), "--cfg", CFG, "--frames", "4",
                         "--max-iters", "2"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = os.path.join(str(tmp_path), "gpurun_out", "train_out", "synthetic", "multi_person_posenet", "synthetic_small")
+    out = os.path.join(str(tmp_path), "output", "synthetic", "multi_person_posenet", "synthetic_small")
     assert os.path.isfile(os.path.join(out, "checkpoint.pth.tar")) and os.path.isfile(os.path.join(out, "final_state.pth.tar"))
     ck = torch.load(os.path.join(out, "checkpoint.pth.tar"), map_location="cpu")
     assert set(ck) >= {"epoch", "state_dict", "precision", "optimizer"}

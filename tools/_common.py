@@ -37,7 +37,8 @@ def make_loader(cfg, frames, batch_per_gpu, rank, world, seed, shuffle):
     ds = SyntheticPanoptic(cfg, num_frames=frames, seed=seed)
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=shuffle) if world > 1 else None
     return torch.utils.data.DataLoader(ds, batch_size=batch_per_gpu, shuffle=(shuffle and sampler is None),
-                                       sampler=sampler, num_workers=0, pin_memory=False)
+                                       sampler=sampler, num_workers=int(cfg.get("WORKERS", 0)), pin_memory=False,
+                                       persistent_workers=False)
 
 
 def save_checkpoint(state, is_best, out_dir, filename="checkpoint.pth.tar"):
