@@ -44,7 +44,7 @@ class PoseRegressionNet(nn.Module):
         return self
 
     @torch.no_grad()
-    def forward_batched(self, all_heatmaps, meta, grid_centers, flip_xcoords=None, max_cubes_per_call: int = 16):
+    def forward_batched(self, all_heatmaps, meta, grid_centers, flip_xcoords=None, max_cubes_per_call: int = 8):
         """All person proposals of a batch at once (inference): grid_centers (B,K,5) -> pred (B,K,J,3).
 
         Replaces the reference's per-candidate loop (lib/models/multi_person_posenet.py:84-88, K
@@ -68,9 +68,18 @@ class PoseRegressionNet(nn.Module):
                                                 channels_last=self.channels_last, sample_of=bi)
         outs = []
         for s0 in range(0, P, max_cubes_per_call):
-            outs.append(_lib.soft_argmax_grid(self.v2v_net(cubes[s0:s0 + max_cubes_per_call]),
-                                              centers[s0:s0 + max_cubes_per_call], self.grid_size, self.cube_size,
-                                              self.soft_argmax_layer.beta))
+            chunk = cubes[s0:s0 + max_cubes_per_call]
+            cen = centers[s0:s0 + max_cubes_per_call]
+            n = chunk.shape[0]
+            # MIOpen re-tunes per distinct batch size: round the tail chunk up to a power of two by
+            # repeating its last cube, so only log2(max)+1 shapes ever reach the conv stack
+            m = 1 << (n - 1).bit_length()
+            if m != n:
+                chunk = torch.cat([chunk, chunk[-1:].expand(m - n, -1, -1, -1, -1)], 0)
+                if self.channels_last:
+                    chunk = chunk.contiguous(memory_format=torch.channels_last_3d)
+            y = self.v2v_net(chunk)[:n]
+            outs.append(_lib.soft_argmax_grid(y, cen, self.grid_size, self.cube_size, self.soft_argmax_layer.beta))
         pred[bi, ki] = torch.cat(outs, 0)
         return pred
 
