@@ -159,7 +159,7 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
                                             valid.data_ptr(), cubes.data_ptr(),
                                             grids.data_ptr() if want_grids else None, B, V, J, h, w, X, Y, Z, gs,
                                             int(img_size[0]), int(img_size[1]),
-                                            int(variant) | (0x100 if channels_last else 0), _stream(dev))
+                                            int(variant) | (0x1000000 if channels_last else 0), _stream(dev))
     check(rc, "sp3d_unproject_fwd")
     return cubes, grids
 

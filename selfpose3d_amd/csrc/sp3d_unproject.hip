@@ -348,7 +348,8 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 
 // NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
 // TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
-template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float, int U = 4, bool PRIO = false>
+template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float, int U = 4, bool PRIO = false,
+          bool PF = false>
 __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
                                                              const float *__restrict__ centers,
                                                              const uint8_t *__restrict__ valid,
@@ -425,53 +426,113 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
-    bool have = P1(0);
+    if constexpr (PF) {
+        // Rotating two-buffer pipeline (U == 2): the taps of the NEXT half-step are always in flight while
+        // the current half-step is accumulated - (c, slots 0-1) -> (c, slots 2-3) -> (c', slots 0-1) ... -
+        // and the projection of view c+1 runs under the first half-step's loads.
+        float4 b0[4][2], b1[4][2];   // [tap][slot] for the even / odd half-step
+        auto issue = [&](float4 (&buf)[4][2], int c, int half) {
+            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+            const int rb = (c & 1) * 320 + g16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const TI *p = vb + wsi[rb + 16 * (half * 2 + k)];
+                buf[0][k] = Store4<TI>::load(p);
+                buf[1][k] = Store4<TI>::load(p + JP);
+                buf[2][k] = Store4<TI>::load(p + rowf);
+                buf[3][k] = Store4<TI>::load(p + rowf + JP);
+            }
+        };
+        auto consume = [&](float4 (&buf)[4][2], int c, int half) {
+            const int rb = (c & 1) * 320 + g16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = half * 2 + k;
+                const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
+                const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
+                float v;
+                v = buf[0][k].x * w00; v = fmaf(buf[1][k].x, w10, v); v = fmaf(buf[2][k].x, w01, v); v = fmaf(buf[3][k].x, w11, v); acc[i][0] = acc[i][0] + v;
+                v = buf[0][k].y * w00; v = fmaf(buf[1][k].y, w10, v); v = fmaf(buf[2][k].y, w01, v); v = fmaf(buf[3][k].y, w11, v); acc[i][1] = acc[i][1] + v;
+                v = buf[0][k].z * w00; v = fmaf(buf[1][k].z, w10, v); v = fmaf(buf[2][k].z, w01, v); v = fmaf(buf[3][k].z, w11, v); acc[i][2] = acc[i][2] + v;
+                v = buf[0][k].w * w00; v = fmaf(buf[1][k].w, w10, v); v = fmaf(buf[2][k].w, w01, v); v = fmaf(buf[3][k].w, w11, v); acc[i][3] = acc[i][3] + v;
+            }
+        };
+        bool have = P1(0);
+        bool prefetched = false;
 #pragma unroll 1
-    for (int c = 0; c < g.V; ++c) {
-        const bool cur = have;
-        const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
-        const int rb = (c & 1) * 320 + g16;
-        if (cur) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // the 4 voxel slots of this lane group are gathered U at a time (4*U dwordx4 loads in flight);
-        // P1(c+1) is scheduled between the first group's loads and its FMAs
-#pragma unroll
-        for (int gi = 0; gi < 4 / U; ++gi) {
-            float4 t00[U], t10[U], t01[U], t11[U];
-            if (cur) {
-                if (PRIO) __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
-                    t00[k] = Store4<TI>::load(p);
-                    t10[k] = Store4<TI>::load(p + JP);
-                    t01[k] = Store4<TI>::load(p + rowf);
-                    t11[k] = Store4<TI>::load(p + rowf + JP);
-                }
-                if (PRIO) __builtin_amdgcn_s_setprio(0);
+        for (int c = 0; c < g.V; ++c) {
+            const bool cur = have;
+            if (cur && !prefetched) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                issue(b0, c, 0);
             }
-            if (gi == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < g.V) have = P1(c + 1); else have = false;
+            __builtin_amdgcn_sched_barrier(0);
+            prefetched = false;
             if (cur) {
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int i = gi * U + k;
-                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                    float v;
-                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
-                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                issue(b1, c, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(b0, c, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) { issue(b0, c + 1, 0); prefetched = true; }
+                __builtin_amdgcn_sched_barrier(0);
+                consume(b1, c, 1);
             }
         }
-    }
+    } else {
+    bool have = P1(0);
+    #pragma unroll 1
+        for (int c = 0; c < g.V; ++c) {
+            const bool cur = have;
+            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+            const int rb = (c & 1) * 320 + g16;
+            if (cur) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the 4 voxel slots of this lane group are gathered U at a time (4*U dwordx4 loads in flight);
+            // P1(c+1) is scheduled between the first group's loads and its FMAs
+    #pragma unroll
+            for (int gi = 0; gi < 4 / U; ++gi) {
+                float4 t00[U], t10[U], t01[U], t11[U];
+                if (cur) {
+                    if (PRIO) __builtin_amdgcn_s_setprio(3);
+    #pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
+                        t00[k] = Store4<TI>::load(p);
+                        t10[k] = Store4<TI>::load(p + JP);
+                        t01[k] = Store4<TI>::load(p + rowf);
+                        t11[k] = Store4<TI>::load(p + rowf + JP);
+                    }
+                    if (PRIO) __builtin_amdgcn_s_setprio(0);
+                }
+                if (gi == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (cur) {
+    #pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const int i = gi * U + k;
+                        const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
+                        const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
+                        float v;
+                        v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
+                        v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
+                        v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
+                        v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
+                    }
+                }
+            }
+        }
+    
+}
 
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
@@ -891,6 +952,11 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
                 return SP3D_EUNSUPPORTED;
             }
         }
+        if ((variant & 256) && nw == 1 && !out_cl) {  // A/B: rotating two-buffer tap pipeline
+            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 4, false, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 4, false, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
+            return SP3D_OK;
+        }
         if ((variant & 128) && nw == 1 && !out_cl) {  // A/B: raised wave priority while issuing the tap loads
             if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 4, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
             else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 4, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
@@ -1094,5 +1160,5 @@ extern "C" int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, 
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
-    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & ~0x100, (variant & 0x100) != 0, 0, (hipStream_t)stream);
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & 0xffffff, (variant & 0x1000000) != 0, 0, (hipStream_t)stream);
 }

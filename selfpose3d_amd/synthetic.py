@@ -202,3 +202,43 @@ def fill_parameters_deterministic(module: torch.nn.Module, seed: int = 0, scale:
                 a = a + 1.0
             t.copy_(torch.from_numpy(a))
     return module
+
+
+def random_meta(batch: int, num_views: int, image_size, seed: int = 0, augment: bool = True, ssv_style: bool = False):
+    """Random calibrated rigs for parity sweeps: per (sample, view) a camera at a random position around the
+    capture space looking roughly at it, random intrinsics / distortion, random original-image size, and
+    (optionally) random crop rotation / scale.  Same dict layout as ``make_meta``."""
+    rng = np.random.default_rng(seed)
+    cdt = torch.float32 if ssv_style else torch.float64
+    metas = []
+    for _ in range(num_views):
+        R, T, fx, fy, cx, cy, k, p, cen, sc, rot = ([] for _ in range(11))
+        for _b in range(batch):
+            ang, rad, hgt = rng.uniform(0, 2 * math.pi), rng.uniform(2500, 6000), rng.uniform(800, 3000)
+            c = np.array([rad * math.cos(ang), -500 + rad * math.sin(ang), hgt])
+            tgt = np.array([rng.uniform(-800, 800), -500 + rng.uniform(-800, 800), rng.uniform(500, 1200)])
+            fwd = (tgt - c) / np.linalg.norm(tgt - c)
+            right = np.cross(fwd, np.array([0.0, 0.0, 1.0])); right /= np.linalg.norm(right)
+            roll = rng.uniform(-0.2, 0.2)
+            down = np.cross(fwd, right)
+            right, down = math.cos(roll) * right + math.sin(roll) * down, -math.sin(roll) * right + math.cos(roll) * down
+            W0, H0 = [(1920, 1080), (1032, 776), (360, 288), (1280, 720)][int(rng.integers(4))]
+            f = rng.uniform(0.6, 1.4) * W0
+            R.append(np.stack([right, down, fwd])); T.append(c.reshape(3, 1))
+            fx.append(f); fy.append(f * rng.uniform(0.97, 1.03))
+            cx.append(W0 / 2 + rng.uniform(-20, 20)); cy.append(H0 / 2 + rng.uniform(-20, 20))
+            k.append(np.array([[rng.uniform(-0.3, 0.1)], [rng.uniform(-0.1, 0.2)], [rng.uniform(-0.05, 0.05)]]))
+            p.append(np.array([[rng.uniform(-2e-3, 2e-3)], [rng.uniform(-2e-3, 2e-3)]]))
+            cen.append([W0 / 2.0, H0 / 2.0])
+            s = get_scale((W0, H0), image_size)
+            if augment:
+                s = (s * np.float32(rng.uniform(0.7, 1.35))).astype(np.float32)
+            sc.append(s)
+            rot.append(float(rng.uniform(-40, 40)) if augment and rng.random() < 0.7 else 0.0)
+        camera = {"R": torch.as_tensor(np.stack(R), dtype=cdt), "T": torch.as_tensor(np.stack(T), dtype=cdt),
+                  "fx": torch.as_tensor(np.array(fx), dtype=cdt), "fy": torch.as_tensor(np.array(fy), dtype=cdt),
+                  "cx": torch.as_tensor(np.array(cx), dtype=cdt), "cy": torch.as_tensor(np.array(cy), dtype=cdt),
+                  "k": torch.as_tensor(np.stack(k), dtype=cdt), "p": torch.as_tensor(np.stack(p), dtype=cdt)}
+        metas.append({"center": torch.tensor(cen, dtype=torch.float64), "scale": torch.as_tensor(np.stack(sc), dtype=torch.float32),
+                      "rotation": torch.tensor(rot, dtype=torch.float64), "camera": camera})
+    return metas
