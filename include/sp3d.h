@@ -131,6 +131,23 @@ int sp3d_unproject_bwd_indexed(const float *const *hm_views, const float *cam, c
                                const float *grid_size, int W_in, int H_in, void *stream);
 
 /*
+ * Training pair with a line-coalesced scatter.  sp3d_unproject_fwd_train = sp3d_unproject_fwd_indexed
+ * (NHWC fp32 input) that also writes pass_mask (P, X*Y*Z) uint16: bit j set where channel j's pre-clamp
+ * value is inside [0,1] and the voxel is not NaN-zeroed - exactly where torch's clamp / index_put_
+ * backward let the gradient through (project_layer.py:97-99).  sp3d_unproject_bwd_packed then needs no
+ * heat-maps: it accumulates into grad_packed (V,B,h,w,Jp) fp32 channels-last, ZERO-FILLED by the caller,
+ * so that one atomic instruction covers whole 64-byte pixels (15x the L2 atomic rate of planar scatter).
+ */
+int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                             const int32_t *sample_of, const float *centers, const uint8_t *valid, float *cubes,
+                             float *grids, uint16_t *pass_mask, int P, int V, int J, int h, int w, int X, int Y, int Z,
+                             const float *grid_size, int W_in, int H_in, void *stream);
+int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                              const float *grad_cubes, const uint16_t *pass_mask, float *grad_packed, int B, int P,
+                              int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
+                              int W_in, int H_in, void *stream);
+
+/*
  * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,
  * lib/models/cuboid_proposal_net.py:42-52): 3x3x3 local-max mask, top-k over the flat volume
  * (ties: larger value, then LOWER flat index), unravel, index -> mm.

@@ -28,6 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed",
 ]
 
 _lib = None
@@ -69,6 +70,10 @@ def load():
     lib.sp3d_unproject_fwd_indexed.argtypes = [P, I, I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_indexed.restype = I
     lib.sp3d_unproject_bwd_indexed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_unproject_fwd_train.restype = I
+    lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_unproject_bwd_packed.restype = I
+    lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_soft_argmax_grid.restype = I
     lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
     lib.sp3d_channel_shift_act.restype = I
@@ -130,7 +135,8 @@ def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch
 def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
                   want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False,
-                  sample_of: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32):
+                  sample_of: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
+                  pass_mask: Optional[torch.Tensor] = None):
     """-> (cubes (B,J,X,Y,Z), grids (B,N,3) | None).  With ``channels_last`` the cubes tensor has
     torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only).
     ``sample_of`` (int32, (B,)): output cube p reads heat-map/camera row sample_of[p] (B = #cubes)."""
@@ -147,7 +153,13 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
         (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
     grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
     gs = _f3(grid_size)
-    if variant is None:
+    if pass_mask is not None:
+        rc = lib.sp3d_unproject_fwd_train(_ptr_array(views), layout | flags, jp, cam.data_ptr(),
+                                          sample_of.data_ptr() if sample_of is not None else None, centers.data_ptr(),
+                                          valid.data_ptr(), cubes.data_ptr(), grids.data_ptr() if want_grids else None,
+                                          pass_mask.data_ptr(), B, V, J, h, w, X, Y, Z, gs, int(img_size[0]),
+                                          int(img_size[1]), _stream(dev))
+    elif variant is None:
         rc = lib.sp3d_unproject_fwd_indexed(_ptr_array(views), layout | flags,
                                             jp, cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                             centers.data_ptr(), valid.data_ptr(), cubes.data_ptr(),
@@ -254,3 +266,21 @@ def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual
     check(lib.sp3d_channel_shift_act(y.data_ptr(), shift.data_ptr(), residual.data_ptr() if residual is not None else None,
                                      int(mode), B, Cc, inner, cl, _stream(y.device)), "sp3d_channel_shift_act")
     return y
+
+
+def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mask: torch.Tensor, batch: int,
+                         num_views: int, J: int, jp: int, h: int, w: int, cube_size, grid_size, img_size,
+                         sample_of: Optional[torch.Tensor] = None):
+    """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer"""
+    lib = load()
+    dev = cam.device
+    P = int(grad_cubes.shape[0])
+    X, Y, Z = (int(c) for c in cube_size)
+    gc = grad_cubes[:, :J].float().contiguous()
+    packed = torch.zeros((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
+    rc = lib.sp3d_unproject_bwd_packed(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
+                                       centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),
+                                       packed.data_ptr(), int(batch), P, num_views, J, jp, h, w, X, Y, Z,
+                                       _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
+    check(rc, "sp3d_unproject_bwd_packed")
+    return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]

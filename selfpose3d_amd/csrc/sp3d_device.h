@@ -31,6 +31,8 @@ struct Geom {
     float stepx, stepy, stepz;    // fp32 (end-start)/(n-1) of torch.linspace, computed on the host (same IEEE ops)
     uint32_t magicYZ, magicZ;     // floor(2^32/d)+1 for d = Y*Z, Z (exact n/d with one fix-up, see udiv_magic)
     const int *sample_of;         // optional (P): heat-map / camera row each output cube reads (NULL: identity)
+    uint16_t *pass_mask;          // optional (P,N): bit j set iff 0 <= pre-clamp value of channel j <= 1 and the
+                                  // voxel is not NaN-zeroed (where torch's clamp / index_put_ let gradient through)
 };
 
 // torch.linspace(-L/2, L/2, n)[i] in fp32 (project_layer.py:28-30; ATen CPU kernel form)
@@ -216,6 +218,13 @@ __device__ __forceinline__ float fuse_rcp(float acc, float den, float rden)
     const float r = fmaf(-q, den, acc);
     const float o = fmaf(r, rden, q);
     return __builtin_amdgcn_fmed3f(o, 0.0f, 1.0f);   // med3(NaN,0,1) = 0: the NaN->0 rule of project_layer.py:98
+}
+
+// pre-clamp quotient of fuse_rcp (for the gradient pass mask)
+__device__ __forceinline__ float fuse_pre(float acc, float den, float rden)
+{
+    const float q = acc * rden;
+    return fmaf(fmaf(-q, den, acc), rden, q);
 }
 
 // ---- storage types: fp32 or bf16 (math is always fp32) -----------------------------------------

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
             float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
             gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
         }
+        if (g.pass_mask && lane < nvox) g.pass_mask[(size_t)b * g.N + n0 + lane] = 0;
         return;
     }
 
@@ -542,6 +543,20 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
         const bool bad = (m & 0x80000000u) != 0;              // NaN sample position: voxel is zero
         const float den = (float)__popc(m & 0x7fffffffu) + 1e-6f;
         const float rden = bad ? 0.0f : 1.0f / den;           // rden = 0 makes fuse_rcp return exactly 0
+        if (g.pass_mask) {
+            // gradient pass mask (torch.clamp backward: 0 <= pre <= 1; NaN-zeroed voxels block it)
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float pre = fuse_pre(acc[i][k], den, rden);
+                if (!bad && pre >= 0.0f && pre <= 1.0f) bits |= 1u << (4 * q + k);
+            }
+            if (!qact) bits = 0;
+            bits |= (uint32_t)__shfl_xor((int)bits, 1);
+            bits |= (uint32_t)__shfl_xor((int)bits, 2);
+            const int nn = 16 * i + g16;
+            if (q == 0 && nn < nvox) g.pass_mask[(size_t)b * g.N + n0 + nn] = (uint16_t)bits;
+        }
         if (OUTCL) {
             // channels-last result (B, N, J): this lane's 4 channels are 16 contiguous bytes, the
             // 4 lanes of a voxel 64 B, the wave's 16 voxels of slot i 1 KiB - no LDS transpose.
@@ -842,6 +857,103 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, line-coalesced scatter ("bwd2").  Needs the pass mask written by the forward pipe kernel,
+// so no heat-map is re-read.  L2 fp32 atomics are one transaction per (instruction, cache line): 64
+// scattered lanes run at 21 G atomics/s, 16 lanes on the 16 channels of one 64-B pixel at 325 G/s
+// (tools/atomic_bench.hip).  Hence: gradients accumulate into a channels-last (V,B,h,w,16) buffer and
+// the scatter maps lane = (voxel-of-4, channel): one atomic instruction = 4 pixels x 16 channels.
+//   P1   lane = voxel: sample records of every view -> LDS (same code as the forward kernel)
+//   load grad tile (J rows of 64 voxels, coalesced) -> LDS, pass mask / view masks per voxel -> LDS
+//   S    lane = (v4, ch): for its 16 voxels, g = pass ? grad / den : 0, then per bound view 4 atomics
+// ------------------------------------------------------------------------------------------
+template <int JP, bool XCD>
+__global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restrict__ cam,
+                                                           const float *__restrict__ centers,
+                                                           const uint8_t *__restrict__ valid,
+                                                           const float *__restrict__ grad_cubes,
+                                                           const uint16_t *__restrict__ pass_mask,
+                                                           float *__restrict__ grad_packed, size_t view_stride,
+                                                           Geom g, int tiles_per_sample)
+{
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
+    float *rec = bsm;                                  // [V][5][64]
+    int *reci = reinterpret_cast<int *>(rec);
+    float *gt = bsm + g.V * 320;                       // [JP][64] gradient tile (0 where masked / beyond J)
+    uint32_t *vm = reinterpret_cast<uint32_t *>(gt + JP * 64);   // [64] view bits per voxel (bit 31: NaN)
+    int b, tile;
+    if (XCD) {
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+    } else {
+        b = blockIdx.x / tiles_per_sample;
+        tile = blockIdx.x - b * tiles_per_sample;
+    }
+    const int n0 = tile * 64;
+    if (n0 >= g.N || !valid[b]) return;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
+    const int lane = threadIdx.x;
+    const int nvox = min(64, g.N - n0);
+    const bool inb = lane < nvox;
+    const int n = n0 + (inb ? lane : 0);
+    int vx, rem, vy, vz;
+    udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
+    udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
+    const float x = linspace_step(g.Lx, g.stepx, g.X, vx) + centers[3 * b + 0];
+    const float y = linspace_step(g.Ly, g.stepy, g.Y, vy) + centers[3 * b + 1];
+    const float z = linspace_step(g.Lz, g.stepz, g.Z, vz) + centers[3 * b + 2];
+    uint32_t mymask = 0;
+    for (int c = 0; c < g.V; ++c) {
+        const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
+        float ix, iy;
+        bool isnan;
+        const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
+        if (bound) mymask |= (1u << c);
+        if (isnan && inb) mymask |= 0x80000000u;
+        const Rec r = make_record<JP>(bound && !isnan, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
+        const int base = c * 320 + lane;
+        reci[base] = r.off;
+        rec[base + 64] = r.w00; rec[base + 128] = r.w10; rec[base + 192] = r.w01; rec[base + 256] = r.w11;
+    }
+    // gradient tile: g = pass ? grad / den : 0     (autograd of project_layer.py:96-99)
+    const uint32_t pm = inb ? (uint32_t)pass_mask[(size_t)b * g.N + n] : 0u;
+    const float den = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+    const bool dead = (mymask & 0x80000000u) != 0 || (mymask & 0x7fffffffu) == 0;
+    const float *gc = grad_cubes + (size_t)b * g.J * g.N + n;
+    bool any = false;
+    for (int j = 0; j < JP; ++j) {
+        float v = 0.0f;
+        if (j < g.J && inb && !dead && ((pm >> j) & 1u)) v = gc[(size_t)j * g.N] / den;
+        any = any || (v != 0.0f);
+        gt[j * 64 + lane] = v;
+    }
+    vm[lane] = any ? (mymask & 0x7fffffffu) : 0u;      // voxels without gradient scatter nothing
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // scatter: lane = (v4, ch)
+    const int v4 = lane >> 4, ch = lane & 15;
+    if (ch >= JP) return;
+    const size_t rowf = (size_t)g.w * JP;
+    float *gbase = grad_packed + (size_t)bs * g.h * rowf + ch;
+#pragma unroll 1
+    for (int m = 0; m < 16; ++m) {
+        const int v = 4 * m + v4;
+        uint32_t views = vm[v];
+        const float gv = gt[ch * 64 + v];
+        while (views) {
+            const int c = __ffs((int)views) - 1;
+            views &= views - 1;
+            const int rb = c * 320 + v;
+            float *p = gbase + (size_t)c * view_stride + reci[rb];
+            const float w00 = rec[rb + 64], w10 = rec[rb + 128], w01 = rec[rb + 192], w11 = rec[rb + 256];
+            if (w00 != 0.0f) unsafeAtomicAdd(p, gv * w00);
+            if (w10 != 0.0f) unsafeAtomicAdd(p + JP, gv * w10);
+            if (w01 != 0.0f) unsafeAtomicAdd(p + rowf, gv * w01);
+            if (w11 != 0.0f) unsafeAtomicAdd(p + rowf + JP, gv * w11);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side helpers
 // ------------------------------------------------------------------------------------------
 static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size,
@@ -857,6 +969,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     if ((int64_t)h * w * 16 > (int64_t)0x7fffffff) return SP3D_ERANGE;
     g.B = B; g.V = V; g.J = J; g.h = h; g.w = w; g.X = X; g.Y = Y; g.Z = Z;
     g.sample_of = nullptr;
+    g.pass_mask = nullptr;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
     g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
@@ -1161,4 +1274,53 @@ extern "C" int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, 
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
     return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, variant & 0xffffff, (variant & 0x1000000) != 0, 0, (hipStream_t)stream);
+}
+
+// forward with the gradient pass mask (uint16 per voxel, bit j = channel j passes gradient) for
+// sp3d_unproject_bwd_packed.  NHWC fp32 input only (the pipelined kernel).
+extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                                        const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                                        float *cubes, float *grids, uint16_t *pass_mask, int P, int V, int J, int h,
+                                        int w, int X, int Y, int Z, const float *grid_size, int W_in, int H_in,
+                                        void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !cubes || !pass_mask) return SP3D_ENULL;
+    if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || (hm_layout & (SP3D_HM_BF16 | SP3D_OUT_BF16)) || w < 2 || h < 2)
+        return SP3D_EUNSUPPORTED;
+    g.sample_of = sample_of;
+    g.pass_mask = pass_mask;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, 24, (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0, 0,
+                       (hipStream_t)stream);
+}
+
+extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers,
+                                         const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
+                                         float *grad_packed, int B, int P, int V, int J, int Jp, int h, int w, int X,
+                                         int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (B <= 0) return SP3D_EINVAL;
+    if (!cam || !centers || !valid || !grad_cubes || !pass_mask || !grad_packed) return SP3D_ENULL;
+    if (Jp < J || (Jp & 3) || Jp > 16 || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
+    g.sample_of = sample_of;
+    const int tiles = (g.N + 63) / 64;
+    const size_t view_stride = (size_t)B * h * w * Jp;
+    const size_t lds = (size_t)(V * 320 + Jp * 64 + 64) * sizeof(float);
+    dim3 grid(xcd_grid_blocks(P, tiles)), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (Jp) {
+    case 4: hipLaunchKernelGGL((unproject_bwd2_kernel<4, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
+    case 8: hipLaunchKernelGGL((unproject_bwd2_kernel<8, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
+    case 12: hipLaunchKernelGGL((unproject_bwd2_kernel<12, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
+    default: hipLaunchKernelGGL((unproject_bwd2_kernel<16, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
+    }
+    return launch_status();
 }

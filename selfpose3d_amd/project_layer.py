@@ -63,13 +63,20 @@ class _UnprojectFn(torch.autograd.Function):
                 _lib.pack_heatmaps(hms, jp=layer.jp_for(J), out_dtype=io)
             jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
+            # when a gradient will be asked for, let the kernel also emit the clamp pass mask: the backward
+            # then runs the line-coalesced scatter without re-reading any heat-map
+            need_grad = io == torch.float32 and any(ctx.needs_input_grad[11:]) and w >= 2 and h >= 2
+            X, Y, Z = cube_size
+            mask = torch.empty((B, X * Y * Z), dtype=torch.int16, device=cam.device) if need_grad else None
             # pad_channels: run the kernel over all jp channels - the padded ones are zero in `packed`,
             # so the extra output channels are exact zeros at no extra cost
             cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, B,
                                               jp if pad_channels else J, h, w, cube_size, grid_size, layer.img_size,
                                               want_grids, channels_last=channels_last, sample_of=sample_of,
-                                              out_dtype=io)
+                                              out_dtype=io, pass_mask=mask)
+            ctx.packed_bwd = (mask, jp, int(heatmaps[0].shape[0]), len(hms), J, h, w) if need_grad else None
         else:
+            ctx.packed_bwd = None
             cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
                                               grid_size, layer.img_size, want_grids, sample_of=sample_of)
         ctx.layer = layer
@@ -85,6 +92,11 @@ class _UnprojectFn(torch.autograd.Function):
     def backward(ctx, grad_cubes, _grad_grids):
         cam, centers, valid, *hms = ctx.saved_tensors
         grid_size, cube_size = ctx.geom
+        if ctx.packed_bwd is not None:
+            mask, jp, batch, nv, J, h, w = ctx.packed_bwd
+            grads = _lib.unproject_bwd_packed(cam, centers, valid, grad_cubes, mask, batch, nv, J, jp, h, w, cube_size,
+                                              grid_size, ctx.layer.img_size, sample_of=ctx.sample_of)
+            return (None,) * 11 + tuple(grads)
         grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size,
                                    sample_of=ctx.sample_of)
         return (None,) * 11 + tuple(grads)

@@ -490,3 +490,40 @@ def test_bf16_storage_config(dev, V):
                                 cube, syn.FINE_GRID_SIZE, img, False, channels_last=True, out_dtype=torch.bfloat16)
     assert ccl.is_contiguous(memory_format=torch.channels_last_3d)
     assert torch.equal(ccl[:, :J].cpu(), ref16) and torch.count_nonzero(ccl[:, J:]) == 0
+
+
+@pytest.mark.parametrize("name", ["unproj_grad_small", "unproj_grad_fine_aug"])
+def test_unproject_bwd_packed_line_coalesced(dev, name):
+    """pass mask from the forward kernel + channels-last scatter == oracle / reference autograd"""
+    from oracle import oracle
+    from selfpose3d_amd import _lib
+    case = gio.Case(name)
+    g = case.g
+    wgt = np.random.default_rng(int(g["grad_seed"])).standard_normal((case.B, case.J, *case.cube)).astype(np.float32)
+    hms = [h.to(dev) for h in case.hms]
+    cam, cen = torch.from_numpy(case.cam).to(dev), torch.from_numpy(case.centers).to(dev)
+    val = torch.from_numpy(case.valid).to(dev)
+    w, h = case.hm
+    jp = 4 if case.J <= 4 else 16
+    packed = _lib.pack_heatmaps(hms, jp=jp)
+    mask = torch.empty((case.B, case.N), dtype=torch.int16, device=dev)
+    cubes, _ = _lib.unproject_fwd([packed[c] for c in range(case.V)], _lib.LAYOUT_NHWC, jp, cam, cen, val, case.B, case.J,
+                                  h, w, case.cube, case.grid_size, case.img, False, pass_mask=mask)
+    exp_c, _, _ = case.expected()
+    assert np.abs(cubes.cpu().numpy().reshape(exp_c.shape) - exp_c).max() <= VOX_TOL
+    grads = _lib.unproject_bwd_packed(cam, cen, val, torch.from_numpy(wgt).to(dev), mask, case.B, case.V, case.J, jp, h, w,
+                                      case.cube, case.grid_size, case.img)
+    ref = oracle.unproject_bwd([x.numpy() for x in case.hms], case.cam, case.centers, case.valid, wgt, case.grid_size,
+                               case.cube, case.img)
+    for c in range(case.V):
+        got = grads[c].cpu().numpy()
+        scale = max(1.0, float(np.abs(ref[c]).max()))
+        assert got.shape == ref[c].shape
+        assert np.abs(got - ref[c]).max() <= 2e-5 * scale
+        assert np.abs(got - g["grad_hm"][c]).max() <= 2e-5 * scale
+    # the pass mask agrees with the pre-clamp values: clamped-at-1 voxels block the gradient
+    m = mask.cpu().numpy().astype(np.uint16)
+    o = cubes.cpu().numpy().reshape(case.B, case.J, case.N)
+    for j in range(case.J):
+        inside = (o[:, j] > 0) & (o[:, j] < 1)
+        assert np.all(((m >> j) & 1)[inside] == 1)
