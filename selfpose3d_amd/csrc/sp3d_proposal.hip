@@ -13,7 +13,7 @@
 namespace sp3d {
 
 constexpr int NMS_THREADS = 256;
-constexpr int NMS_PER_THREAD = 8;
+constexpr int NMS_PER_THREAD = 2;
 constexpr int NMS_CHUNK = NMS_THREADS * NMS_PER_THREAD;
 
 struct Cand {
@@ -116,7 +116,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float
     }
 }
 
-// stage 2: one workgroup per sample merges nchunks*k candidates, unravels and converts to mm
+// stage 2: one workgroup per sample merges nchunks*k candidates, unravels and converts to mm.
+// Every thread keeps its strided share of the candidates in registers (<= MERGE_PER_THREAD), so the k
+// selection rounds touch no memory; larger candidate sets fall back to the in-memory loop.
+constexpr int MERGE_PER_THREAD = 16;
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict__ ws, int ncand, int X, int Y, int Z,
                                                                int k, float Lx, float Ly, float Lz, float cx, float cy,
                                                                float cz, float *__restrict__ vals,
@@ -127,16 +131,39 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict
     const int b = blockIdx.x;
     Cand *cand = ws + (size_t)b * ncand;
     const int YZ = Y * Z;
+    const bool inreg = ncand <= NMS_THREADS * MERGE_PER_THREAD;
+    Cand mine[MERGE_PER_THREAD];
+    if (inreg) {
+#pragma unroll
+        for (int e = 0; e < MERGE_PER_THREAD; ++e) {
+            const int i = e * NMS_THREADS + threadIdx.x;
+            if (i < ncand) mine[e] = cand[i];
+            else { mine[e].v = -INFINITY; mine[e].i = 0x7fffffff; }
+        }
+    }
     for (int t = 0; t < k; ++t) {
         Cand best;
         best.v = -INFINITY; best.i = 0x7fffffff;
-        for (int e = threadIdx.x; e < ncand; e += NMS_THREADS) {
-            const Cand c = cand[e];
-            if (better(c, best)) best = c;
+        if (inreg) {
+#pragma unroll
+            for (int e = 0; e < MERGE_PER_THREAD; ++e)
+                if (better(mine[e], best)) best = mine[e];
+        } else {
+            for (int e = threadIdx.x; e < ncand; e += NMS_THREADS) {
+                const Cand c = cand[e];
+                if (better(c, best)) best = c;
+            }
         }
         const Cand win = block_best(best, sv, si);
-        for (int e = threadIdx.x; e < ncand; e += NMS_THREADS)
-            if (cand[e].i == win.i) { cand[e].v = -INFINITY; cand[e].i = 0x7fffffff; }
+        if (inreg) {
+#pragma unroll
+            for (int e = 0; e < MERGE_PER_THREAD; ++e)
+                if (mine[e].i == win.i) { mine[e].v = -INFINITY; mine[e].i = 0x7fffffff; }
+        } else {
+            for (int e = threadIdx.x; e < ncand; e += NMS_THREADS)
+                if (cand[e].i == win.i) { cand[e].v = -INFINITY; cand[e].i = 0x7fffffff; }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
             const int n = win.i == 0x7fffffff ? 0 : win.i;
             const int ix = n / YZ, iy = (n % YZ) / Z, iz = n % Z;          // core/proposal.py:21-23
@@ -150,7 +177,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict
                 lp[2] = ((float)iz / (float)(Z - 1) * Lz + cz) - Lz / 2.0f;
             }
         }
-        __syncthreads();
     }
 }
 
