@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-baseline-reps", type=int, default=6)
     ap.add_argument("--v2v-layout", choices=["ncdhw", "cl3d"], default="cl3d",
                     help="memory format of the V2V stack (fp32 either way)")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one HIP graph")
     ap.add_argument("--cold", action="store_true", help="also time the kernel rotating >256 MiB of inputs (MALL-cold)")
     return ap.parse_args()
 
@@ -191,9 +192,28 @@ def main():
     torch.backends.cudnn.benchmark = True
     cfg, meta, hms, model = build_workload(args.batch, rank, dev, args.v2v_layout)
 
-    def step():
+    from selfpose3d_amd.project_layer import clear_pack_cache
+
+    def eager_step():
+        # every step is a FRESH batch: drop the per-batch caches (re-tiled heat-maps, camera table) so the
+        # timed region contains the host camera pack + upload, the pack kernel and the unprojection
+        clear_pack_cache()
+        model.project_layer._cam_key = None
         with torch.no_grad():
             return model(hms, meta)
+
+    step, mode = eager_step, "eager"
+    if not args.no_graph:
+        try:
+            for _ in range(2):
+                eager_step()                       # MIOpen algorithm search must happen outside capture
+            torch.cuda.synchronize(dev)
+            from selfpose3d_amd.graphs import GraphedRootNet
+            graphed = GraphedRootNet(model, hms, meta)
+            step, mode = (lambda: graphed()), "hipgraph"
+        except Exception as e:                     # capture not possible: stay on the eager HIP path
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            step, mode = eager_step, "eager"
 
     for _ in range(args.warmup):
         step()
@@ -226,7 +246,7 @@ def main():
                        "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
                        "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
                        "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(MIOpen fp32) -> NMS/top-k(HIP)",
-                       "v2v_layout": args.v2v_layout},
+                       "v2v_layout": args.v2v_layout, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
         }
         result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, cold=args.cold)

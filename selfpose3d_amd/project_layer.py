@@ -124,22 +124,54 @@ class ProjectLayer(nn.Module):
 
     # -- host side -----------------------------------------------------------------------
     def camera_table(self, meta: Sequence[dict], batch: int, flip_xcoords, device) -> torch.Tensor:
+        """(B,V,32) fp32 table on `device`; rebuilt only when `meta` / flip change.  The upload is one
+        asynchronous copy from a small ring of pinned staging buffers (no host<->GPU synchronisation,
+        unlike the ~6 blocking transfers per (sample, view) of the reference, transforms.py:67-72)."""
         key = (meta_cache_key(meta, flip_xcoords, self.img_size), batch, str(device))
         if key != self._cam_key:
-            tab = pack_cameras(meta, batch, self.img_size, flip_xcoords)
-            self._cam_dev = torch.from_numpy(tab).to(device, non_blocking=False)
+            tab = torch.from_numpy(pack_cameras(meta, batch, self.img_size, flip_xcoords))
+            if device.type == "cuda":
+                ring = self.__dict__.setdefault("_cam_ring", [])
+                slot = self.__dict__.get("_cam_slot", 0)
+                if len(ring) < 4 or ring[slot][0].shape != tab.shape:
+                    entry = [torch.empty_like(tab).pin_memory(), torch.cuda.Event()]
+                    if len(ring) < 4:
+                        ring.append(entry)
+                        slot = len(ring) - 1
+                    else:
+                        ring[slot] = entry
+                else:
+                    ring[slot][1].synchronize()          # the copy that last used this staging buffer is long done
+                pinned, ev = ring[slot]
+                pinned.copy_(tab)
+                dev_tab = torch.empty(tab.shape, dtype=torch.float32, device=device)
+                dev_tab.copy_(pinned, non_blocking=True)
+                ev.record(torch.cuda.current_stream(device))
+                self.__dict__["_cam_slot"] = (slot + 1) % 4
+                self._cam_dev = dev_tab
+            else:
+                self._cam_dev = tab.to(device)
             self._cam_key = key
         return self._cam_dev
 
+    _CONST_CENTERS: "dict[tuple, tuple]" = {}
+
     @staticmethod
     def centers_valid(grid_center, batch: int, device):
-        """(centers (B,3) fp32, valid (B) uint8) following project_layer.py:54,58-61."""
+        """(centers (B,3) fp32, valid (B) uint8) following project_layer.py:54,58-61.  A host-side list
+        centre (the shared coarse-grid centre from the config) is uploaded once and reused - no per-call
+        host->device copy, which also keeps the call HIP-graph capturable."""
         if isinstance(grid_center, torch.Tensor):
             gc = grid_center.to(device=device, dtype=torch.float32)
             if gc.dim() == 1:
                 gc = gc[None]
         else:
-            gc = torch.as_tensor(np.asarray(grid_center, dtype=np.float32), device=device)
+            arr = np.asarray(grid_center, dtype=np.float32)
+            key = (arr.tobytes(), arr.shape, int(batch), str(device))
+            hit = ProjectLayer._CONST_CENTERS.get(key)
+            if hit is not None:
+                return hit
+            gc = torch.as_tensor(arr, device=device)
         rows, cols = gc.shape
         if cols == 3:                       # `len(grid_center[0]) == 3`: always valid
             valid = torch.ones(batch, dtype=torch.uint8, device=device)
@@ -149,7 +181,12 @@ class ProjectLayer(nn.Module):
         centers = gc[:, :3]
         if rows == 1 and batch > 1:         # `len(grid_center) == 1`: shared centre
             centers = centers.expand(batch, 3)
-        return centers.contiguous(), valid.contiguous()
+        out = (centers.contiguous(), valid.contiguous())
+        if not isinstance(grid_center, torch.Tensor):
+            if len(ProjectLayer._CONST_CENTERS) > 64:
+                ProjectLayer._CONST_CENTERS.clear()
+            ProjectLayer._CONST_CENTERS[key] = out
+        return out
 
     # -- reference API -------------------------------------------------------------------
     def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True,

@@ -89,3 +89,36 @@ def test_rootnet_soft_forward_and_synthetic_training_branch():
     loss = torch.nn.functional.mse_loss(syn_cubes, target)
     loss.backward()
     assert soft.v2v_net.output_layer.weight.grad is not None
+
+
+def test_hip_graph_replay_matches_eager_and_tracks_new_inputs():
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    from selfpose3d_amd.graphs import GraphedRootNet
+    dev = torch.device("cuda:0")
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[384, 288], NETWORK__HEATMAP_SIZE=[96, 72],
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[24, 24, 8])
+    B, V, J = 2, 5, 15
+    meta = syn.make_meta(B, V, (384, 288))
+    hms_a = [h.to(dev) for h in syn.people_heatmaps(B, V, J, 72, 96, (384, 288), seed=1)[0]]
+    hms_b = [h.to(dev) for h in syn.people_heatmaps(B, V, J, 72, 96, (384, 288), seed=2)[0]]
+    net = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=4, scale=0.05)
+    net.eval().to(dev).use_channels_last(True)
+    with torch.no_grad():
+        ref_a = [t.clone() for t in net(hms_a, meta)]
+        ref_b = [t.clone() for t in net(hms_b, meta)]
+        meta2 = syn.make_meta(B, V, (384, 288), rotations=[5.0, -5.0], scale_mults=[1.1, 0.9], ssv_style=True)
+        ref_c = [t.clone() for t in net(hms_b, meta2)]
+    static = [h.clone() for h in hms_a]
+    g = GraphedRootNet(net, static, meta)
+    out = g()
+    assert torch.equal(out[0], ref_a[0]) and torch.equal(out[1], ref_a[1])
+    for s, h in zip(static, hms_b):                 # new frame written into the static input buffers
+        s.copy_(h)
+    out = g()
+    assert torch.equal(out[0], ref_b[0]) and torch.equal(out[1], ref_b[1])
+    # new calibration (different crop scale) reaches the kernels through the pinned camera table
+    out2 = g(meta2)
+    assert torch.equal(out2[0], ref_c[0]) and torch.equal(out2[1], ref_c[1]) and not torch.equal(out2[0], ref_b[0])
