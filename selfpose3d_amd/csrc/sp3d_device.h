@@ -31,6 +31,7 @@ struct Geom {
     float stepx, stepy, stepz;    // fp32 (end-start)/(n-1) of torch.linspace, computed on the host (same IEEE ops)
     uint32_t magicYZ, magicZ;     // floor(2^32/d)+1 for d = Y*Z, Z (exact n/d with one fix-up, see udiv_magic)
     const int *sample_of;         // optional (P): heat-map / camera row each output cube reads (NULL: identity)
+    int xcd_chunk;                // tiles per chunk of the XCD-affine tile map (power of two)
     uint16_t *pass_mask;          // optional (P,N): bit j set iff 0 <= pre-clamp value of channel j <= 1 and the
                                   // voxel is not NaN-zeroed (where torch's clamp / index_put_ let gradient through)
 };
@@ -270,21 +271,30 @@ template <> struct Store4<bf16_t> {
 //   B  > 8, B % 8 == 0 : XCD x serves samples x, x+8, ... whole
 //   otherwise          : plain interleave (tile-major order), still correct, less affinity
 // returns false if this block has no work.  grid size: xcd_grid_blocks().
-__host__ __device__ __forceinline__ int xcd_slots_per_xcd(int B, int tiles)
+// K = tiles per dealt chunk (power of two): a sample's tiles go to its XCDs in chunks of K consecutive
+// tiles - larger K keeps each XCD on a compact part of the volume (fewer distinct heat-map lines per
+// L2), smaller K balances the load better.  K comes from Geom::xcd_chunk.
+__host__ __device__ __forceinline__ int xcd_slots_per_xcd(int B, int tiles, int K)
 {
-    if (B <= 8 && (8 % B) == 0) { const int xps = 8 / B; return (tiles + xps - 1) / xps; }
+    if (B <= 8 && (8 % B) == 0) {
+        const int xps = 8 / B;
+        const int chunks = (tiles + K - 1) / K;
+        return ((chunks + xps - 1) / xps) * K;
+    }
     if (B > 8 && (B % 8) == 0) return (B / 8) * tiles;
     return (B * tiles + 7) / 8;
 }
-__host__ __device__ __forceinline__ int xcd_grid_blocks(int B, int tiles) { return 8 * xcd_slots_per_xcd(B, tiles); }
+__host__ __device__ __forceinline__ int xcd_grid_blocks(int B, int tiles, int K) { return 8 * xcd_slots_per_xcd(B, tiles, K); }
 
-__device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int &b, int &tile)
+__device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int K, int &b, int &tile)
 {
     const int x = bid & 7, slot = bid >> 3;
     if (B <= 8 && (8 % B) == 0) {
         const int xps = 8 / B;
         b = x / xps;
-        tile = slot * xps + (x - b * xps);
+        const int sub = x - b * xps;
+        const int chunk = (slot / K) * xps + sub;
+        tile = chunk * K + (slot & (K - 1));
         return tile < tiles;
     }
     if (B > 8 && (B % 8) == 0) {

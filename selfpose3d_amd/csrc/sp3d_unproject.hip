@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
 
     int b, tile;
     if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
     } else {
         b = blockIdx.x / tiles_per_sample;
         tile = blockIdx.x - b * tiles_per_sample;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
 
     int b, tile;
     if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
     } else {
         b = blockIdx.x / tiles_per_sample;
         tile = blockIdx.x - b * tiles_per_sample;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64) void unproject_persist_kernel(Views hm, const f
     auto next_tile = [&](Tile &t) -> bool {
         for (; vb < vgrid; vb += gridDim.x) {
             int b, tile;
-            if (!xcd_map(vb, g.B, tiles_per_sample, b, tile)) continue;
+            if (!xcd_map(vb, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) continue;
             const int n0 = tile * 64;
             if (n0 >= g.N) continue;
             const int nvox = min(64, g.N - n0);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
     uint32_t *vm = reinterpret_cast<uint32_t *>(gt + JP * 64);   // [64] view bits per voxel (bit 31: NaN)
     int b, tile;
     if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, b, tile)) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
     } else {
         b = blockIdx.x / tiles_per_sample;
         tile = blockIdx.x - b * tiles_per_sample;
@@ -970,6 +970,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.B = B; g.V = V; g.J = J; g.h = h; g.w = w; g.X = X; g.Y = Y; g.Z = Z;
     g.sample_of = nullptr;
     g.pass_mask = nullptr;
+    g.xcd_chunk = 1;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
     g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
@@ -1020,11 +1021,11 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
     const int total = tiles * g.B;
     const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
     const bool xcd = !(variant & 4);
-    dim3 grid(xcd ? xcd_grid_blocks(g.B, tiles) : total), block(TILE);
+    dim3 grid(xcd ? xcd_grid_blocks(g.B, tiles, g.xcd_chunk) : total), block(TILE);
     if ((variant & 64) && io == 0) {   // persistent waves (fp32 storage)
         const int wpc = ((variant >> 12) & 31) ? ((variant >> 12) & 31) : 8;       // resident waves per CU
         const int ptiles = (g.N + 63) / 64;
-        const int vgrid = xcd_grid_blocks(g.B, ptiles);
+        const int vgrid = xcd_grid_blocks(g.B, ptiles, g.xcd_chunk);
         int G = 256 * wpc;
         if (G > vgrid) G = vgrid;
         G = ((G + 7) / 8) * 8;
@@ -1037,7 +1038,7 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         const int nw = (variant & 16) ? 1 : 4;
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
         const int ptotal = ptiles * g.B;
-        dim3 pgrid(xcd ? xcd_grid_blocks(g.B, ptiles) : ptotal), pblock(64 * nw);
+        dim3 pgrid(xcd ? xcd_grid_blocks(g.B, ptiles, g.xcd_chunk) : ptotal), pblock(64 * nw);
 #define SP3D_PIPE(XCD_, NW_, CL_) \
     hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
 #define SP3D_PIPE_T(XCD_, CL_, TI_, TO_) \
@@ -1105,8 +1106,20 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
 
 // io: bit 0 = packed heat-maps are bf16, bit 1 = cubes are bf16
 static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *centers, const uint8_t *valid,
-                       float *cubes, float *grids, const Geom &g, int variant, bool out_cl, int io, hipStream_t s)
+                       float *cubes, float *grids, const Geom &g_in, int variant, bool out_cl, int io, hipStream_t s)
 {
+    Geom g = g_in;
+    if ((variant >> 17) & 15) {
+        g.xcd_chunk = 1 << (((variant >> 17) & 15) - 1);   // tuning bits 17-20: log2(K)+1
+    } else {
+        // default: 2-4 chunks per serving XCD - compact enough that an XCD's L2 sees a fraction of each
+        // view (fabric reads 93 MB -> 81 MB on the bench workload), fine enough to balance visibility
+        const int xps = (g.B <= 8 && (8 % g.B) == 0) ? 8 / g.B : 1;
+        const int t64 = (g.N + 63) / 64;
+        int k = 1;
+        while (k * 2 * xps * 2 <= t64) k *= 2;
+        g.xcd_chunk = k;
+    }
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
     if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;    // the clamped 2x2 block needs a 2x2 image
@@ -1314,7 +1327,7 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
     const int tiles = (g.N + 63) / 64;
     const size_t view_stride = (size_t)B * h * w * Jp;
     const size_t lds = (size_t)(V * 320 + Jp * 64 + 64) * sizeof(float);
-    dim3 grid(xcd_grid_blocks(P, tiles)), block(64);
+    dim3 grid(xcd_grid_blocks(P, tiles, g.xcd_chunk)), block(64);
     hipStream_t s = (hipStream_t)stream;
     switch (Jp) {
     case 4: hipLaunchKernelGGL((unproject_bwd2_kernel<4, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
