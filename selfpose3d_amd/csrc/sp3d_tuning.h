@@ -6,10 +6,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* variant: bits[1:0] voxels in flight (old NHWC kernel); bit 2: no XCD-affine tile map; bit 3: pipelined
- * per-wave kernel; bit 4: one wave per workgroup; bit 5: 2 slots in flight; bit 6: persistent waves
- * (bits 12-16: waves per CU); bit 7: s_setprio around loads; bit 8: rotating two-buffer tap pipeline;
- * bit 24: channels-last output */
+/* variant: bits[1:0] voxels in flight (first NHWC kernel); bit 2: no XCD-affine tile map; bit 3: pipelined
+ * per-wave kernel; bit 4: one wave per workgroup; bits 17-20: log2(tiles per XCD chunk)+1; bit 24:
+ * channels-last output.  Library default: 24. */
 int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float *cam, const float *centers,
                                const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w,
                                int X, int Y, int Z, const float *grid_size, int W_in, int H_in, int variant,

@@ -348,15 +348,15 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 
 // NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
 // TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
-template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float, int U = 4, bool PRIO = false,
-          bool PF = false>
-__global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
+template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
                                                              const float *__restrict__ centers,
                                                              const uint8_t *__restrict__ valid,
                                                              float *__restrict__ cubes, float *__restrict__ grids,
                                                              Geom g, int tiles_per_sample, int total_tiles)
 {
     constexpr int NQ = JP / 4;
+    constexpr int U = 4;                      // voxel slots gathered per batch of loads (2 and 1 measured equal)
     constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
     __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
 
@@ -427,113 +427,51 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
-    if constexpr (PF) {
-        // Rotating two-buffer pipeline (U == 2): the taps of the NEXT half-step are always in flight while
-        // the current half-step is accumulated - (c, slots 0-1) -> (c, slots 2-3) -> (c', slots 0-1) ... -
-        // and the projection of view c+1 runs under the first half-step's loads.
-        float4 b0[4][2], b1[4][2];   // [tap][slot] for the even / odd half-step
-        auto issue = [&](float4 (&buf)[4][2], int c, int half) {
-            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
-            const int rb = (c & 1) * 320 + g16;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const TI *p = vb + wsi[rb + 16 * (half * 2 + k)];
-                buf[0][k] = Store4<TI>::load(p);
-                buf[1][k] = Store4<TI>::load(p + JP);
-                buf[2][k] = Store4<TI>::load(p + rowf);
-                buf[3][k] = Store4<TI>::load(p + rowf + JP);
-            }
-        };
-        auto consume = [&](float4 (&buf)[4][2], int c, int half) {
-            const int rb = (c & 1) * 320 + g16;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = half * 2 + k;
-                const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                float v;
-                v = buf[0][k].x * w00; v = fmaf(buf[1][k].x, w10, v); v = fmaf(buf[2][k].x, w01, v); v = fmaf(buf[3][k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                v = buf[0][k].y * w00; v = fmaf(buf[1][k].y, w10, v); v = fmaf(buf[2][k].y, w01, v); v = fmaf(buf[3][k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                v = buf[0][k].z * w00; v = fmaf(buf[1][k].z, w10, v); v = fmaf(buf[2][k].z, w01, v); v = fmaf(buf[3][k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                v = buf[0][k].w * w00; v = fmaf(buf[1][k].w, w10, v); v = fmaf(buf[2][k].w, w01, v); v = fmaf(buf[3][k].w, w11, v); acc[i][3] = acc[i][3] + v;
-            }
-        };
-        bool have = P1(0);
-        bool prefetched = false;
-#pragma unroll 1
-        for (int c = 0; c < g.V; ++c) {
-            const bool cur = have;
-            if (cur && !prefetched) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                issue(b0, c, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < g.V) have = P1(c + 1); else have = false;
-            __builtin_amdgcn_sched_barrier(0);
-            prefetched = false;
-            if (cur) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                issue(b1, c, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(b0, c, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (have) { issue(b0, c + 1, 0); prefetched = true; }
-                __builtin_amdgcn_sched_barrier(0);
-                consume(b1, c, 1);
-            }
-        }
-    } else {
     bool have = P1(0);
-    #pragma unroll 1
-        for (int c = 0; c < g.V; ++c) {
-            const bool cur = have;
-            const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
-            const int rb = (c & 1) * 320 + g16;
+#pragma unroll 1
+    for (int c = 0; c < g.V; ++c) {
+        const bool cur = have;
+        const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+        const int rb = (c & 1) * 320 + g16;
+        if (cur) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the 4 voxel slots of this lane group are gathered U at a time (4*U dwordx4 loads in flight);
+        // P1(c+1) is scheduled between the first group's loads and its FMAs
+#pragma unroll
+        for (int gi = 0; gi < 4 / U; ++gi) {
+            float4 t00[U], t10[U], t01[U], t11[U];
             if (cur) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
+                    t00[k] = Store4<TI>::load(p);
+                    t10[k] = Store4<TI>::load(p + JP);
+                    t01[k] = Store4<TI>::load(p + rowf);
+                    t11[k] = Store4<TI>::load(p + rowf + JP);
+                }
             }
-            // the 4 voxel slots of this lane group are gathered U at a time (4*U dwordx4 loads in flight);
-            // P1(c+1) is scheduled between the first group's loads and its FMAs
-    #pragma unroll
-            for (int gi = 0; gi < 4 / U; ++gi) {
-                float4 t00[U], t10[U], t01[U], t11[U];
-                if (cur) {
-                    if (PRIO) __builtin_amdgcn_s_setprio(3);
-    #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
-                        t00[k] = Store4<TI>::load(p);
-                        t10[k] = Store4<TI>::load(p + JP);
-                        t01[k] = Store4<TI>::load(p + rowf);
-                        t11[k] = Store4<TI>::load(p + rowf + JP);
-                    }
-                    if (PRIO) __builtin_amdgcn_s_setprio(0);
-                }
-                if (gi == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (cur) {
-    #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const int i = gi * U + k;
-                        const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                        const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                        float v;
-                        v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                        v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                        v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                        v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
-                    }
+            if (gi == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cur) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int i = gi * U + k;
+                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
+                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
+                    float v;
+                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
+                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
+                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
+                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
                 }
             }
         }
-    
-}
+    }
 
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
@@ -585,180 +523,6 @@ __global__ __launch_bounds__(64 * NW, (U == 2 ? 5 : 1)) void unproject_pipe_kern
     } else {
         for (int j = 0; j < g.J; ++j)
             if (lane < nvox) Store4<TO>::store1(cb + (size_t)j * g.N + n0 + lane, ws[j * WOSTR + lane]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// persistent variant of the pipelined kernel: a fixed population of waves walks the (sample, tile)
-// list; while the taps of view c of the CURRENT tile are in flight the wave projects view c-1 of its
-// NEXT tile (record slot c-1 has just been consumed), so the projection VALU work of tile t+1 hides
-// under the gather of tile t instead of preceding it.  Same arithmetic, same bits.
-// ------------------------------------------------------------------------------------------
-template <int JP, bool OUTCL>
-__global__ __launch_bounds__(64) void unproject_persist_kernel(Views hm, const float *__restrict__ cam,
-                                                              const float *__restrict__ centers,
-                                                              const uint8_t *__restrict__ valid,
-                                                              float *__restrict__ cubes, float *__restrict__ grids,
-                                                              Geom g, int tiles_per_sample, int vgrid)
-{
-    constexpr int NQ = JP / 4;
-    extern __shared__ __attribute__((aligned(16))) float psm[];
-    float *rec = psm;                                 // [V][5][64] sample records of the tile being gathered / refilled
-    int *reci = reinterpret_cast<int *>(rec);
-    float *sout = psm + g.V * 320;                    // [JP][WOSTR] result tile (planar output only)
-    const int lane = threadIdx.x;
-    const int g16 = lane >> 2, q = lane & 3;
-    const bool qact = q < NQ;
-    const size_t rowf = (size_t)g.w * JP;
-
-    struct Tile {
-        int b, bs, n0, nvox;
-        float x, y, z;
-        uint32_t mask;     // bound bits of this lane's voxel (+ bit 31: NaN position)
-        uint32_t amask;    // wave-uniform: views some voxel of the tile sees
-    };
-
-    int vb = blockIdx.x;
-    // fetch the next tile with work (zero-filling tiles of skipped samples on the way)
-    auto next_tile = [&](Tile &t) -> bool {
-        for (; vb < vgrid; vb += gridDim.x) {
-            int b, tile;
-            if (!xcd_map(vb, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) continue;
-            const int n0 = tile * 64;
-            if (n0 >= g.N) continue;
-            const int nvox = min(64, g.N - n0);
-            if (!valid[b]) {                           // project_layer.py:48,51,54
-                float *cb = cubes + (size_t)b * g.J * g.N;
-                for (int j = 0; j < g.J; ++j)
-                    if (lane < nvox) cb[OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)] = 0.0f;
-                if (grids && lane < nvox) {
-                    float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
-                    gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
-                }
-                continue;
-            }
-            t.b = b; t.bs = g.sample_of ? g.sample_of[b] : b; t.n0 = n0; t.nvox = nvox;
-            const int n = n0 + (lane < nvox ? lane : 0);
-            int vx, rem, vy, vz;
-            udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
-            udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
-            t.x = linspace_step(g.Lx, g.stepx, g.X, vx) + centers[3 * b + 0];
-            t.y = linspace_step(g.Ly, g.stepy, g.Y, vy) + centers[3 * b + 1];
-            t.z = linspace_step(g.Lz, g.stepz, g.Z, vz) + centers[3 * b + 2];
-            if (grids && lane < nvox) {
-                float *gp = grids + ((size_t)b * g.N + n) * 3;
-                gp[0] = t.x; gp[1] = t.y; gp[2] = t.z;
-            }
-            t.mask = 0; t.amask = 0;
-            vb += gridDim.x;
-            return true;
-        }
-        return false;
-    };
-
-    auto P1 = [&](Tile &t, int c) {
-        const float *cm = cam + ((size_t)t.bs * g.V + c) * SP3D_CAM_STRIDE;
-        float ix, iy;
-        bool isnan;
-        const bool inb = lane < t.nvox;
-        const bool bound = sample_pos_fast(cm, t.x, t.y, t.z, g, ix, iy, isnan) && inb;
-        if (bound) t.mask |= (1u << c);
-        if (isnan && inb) t.mask |= 0x80000000u;
-        const bool use = bound && !isnan;
-        if (!__any(use)) return;
-        t.amask |= (1u << c);
-        const Rec r = make_record<JP>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
-        const int base = c * 320 + lane;
-        reci[base] = r.off;
-        rec[base + 64] = r.w00; rec[base + 128] = r.w10; rec[base + 192] = r.w01; rec[base + 256] = r.w11;
-    };
-
-    Tile cur;
-    if (!next_tile(cur)) return;
-    for (int c = 0; c < g.V; ++c) P1(cur, c);
-
-    while (true) {
-        Tile nxt;
-        const bool have_next = next_tile(nxt);
-        float acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-        int pn = 0;
-#pragma unroll 1
-        for (int c = 0; c < g.V; ++c) {
-            const bool active = (cur.amask >> c) & 1u;
-            float4 t00[4], t10[4], t01[4], t11[4];
-            const int rb = c * 320 + g16;
-            if (active) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const float *vbp = hm.p[c] + (size_t)cur.bs * g.h * rowf + (qact ? 4 * q : 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float *p = vbp + reci[rb + 16 * i];
-                    t00[i] = *reinterpret_cast<const float4 *>(p);
-                    t10[i] = *reinterpret_cast<const float4 *>(p + JP);
-                    t01[i] = *reinterpret_cast<const float4 *>(p + rowf);
-                    t11[i] = *reinterpret_cast<const float4 *>(p + rowf + JP);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (have_next && pn < c) { P1(nxt, pn); ++pn; }   // slot pn was consumed by view pn's FMAs
-            __builtin_amdgcn_sched_barrier(0);
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float w00 = rec[rb + 16 * i + 64], w10 = rec[rb + 16 * i + 128];
-                    const float w01 = rec[rb + 16 * i + 192], w11 = rec[rb + 16 * i + 256];
-                    float v;
-                    v = t00[i].x * w00; v = fmaf(t10[i].x, w10, v); v = fmaf(t01[i].x, w01, v); v = fmaf(t11[i].x, w11, v); acc[i][0] = acc[i][0] + v;
-                    v = t00[i].y * w00; v = fmaf(t10[i].y, w10, v); v = fmaf(t01[i].y, w01, v); v = fmaf(t11[i].y, w11, v); acc[i][1] = acc[i][1] + v;
-                    v = t00[i].z * w00; v = fmaf(t10[i].z, w10, v); v = fmaf(t01[i].z, w01, v); v = fmaf(t11[i].z, w11, v); acc[i][2] = acc[i][2] + v;
-                    v = t00[i].w * w00; v = fmaf(t10[i].w, w10, v); v = fmaf(t01[i].w, w01, v); v = fmaf(t11[i].w, w11, v); acc[i][3] = acc[i][3] + v;
-                }
-            }
-        }
-
-        // view fusion + store of the finished tile
-        float *cb = cubes + (size_t)cur.b * g.J * g.N;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = (uint32_t)__shfl((int)cur.mask, 16 * i + g16);
-            const bool bad = (m & 0x80000000u) != 0;
-            const float den = (float)__popc(m & 0x7fffffffu) + 1e-6f;
-            const float rden = bad ? 0.0f : 1.0f / den;
-            if (OUTCL) {
-                const int nn = 16 * i + g16;
-                if (qact && 4 * q < g.J && nn < cur.nvox) {
-                    float4 o;
-                    o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
-                    o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                    *reinterpret_cast<float4 *>(cb + (size_t)(cur.n0 + nn) * g.J + 4 * q) = o;
-                }
-            } else if (qact) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sout[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
-            }
-        }
-        if (!OUTCL) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (((g.N & 3) == 0) && cur.nvox == 64) {
-                for (int j = lane >> 4; j < g.J; j += 4) {
-                    const int u = lane & 15;
-                    const float4 o = *reinterpret_cast<const float4 *>(&sout[j * WOSTR + 4 * u]);
-                    *reinterpret_cast<float4 *>(cb + (size_t)j * g.N + cur.n0 + 4 * u) = o;
-                }
-            } else {
-                for (int j = 0; j < g.J; ++j)
-                    if (lane < cur.nvox) cb[(size_t)j * g.N + cur.n0 + lane] = sout[j * WOSTR + lane];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (!have_next) break;
-        for (; pn < g.V; ++pn) P1(nxt, pn);
-        cur = nxt;
     }
 }
 
@@ -1022,18 +786,6 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
     const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
     const bool xcd = !(variant & 4);
     dim3 grid(xcd ? xcd_grid_blocks(g.B, tiles, g.xcd_chunk) : total), block(TILE);
-    if ((variant & 64) && io == 0) {   // persistent waves (fp32 storage)
-        const int wpc = ((variant >> 12) & 31) ? ((variant >> 12) & 31) : 8;       // resident waves per CU
-        const int ptiles = (g.N + 63) / 64;
-        const int vgrid = xcd_grid_blocks(g.B, ptiles, g.xcd_chunk);
-        int G = 256 * wpc;
-        if (G > vgrid) G = vgrid;
-        G = ((G + 7) / 8) * 8;
-        const size_t lds = (size_t)(g.V * 320 + (out_cl ? 0 : JP * WOSTR)) * sizeof(float);
-        if (out_cl) hipLaunchKernelGGL((unproject_persist_kernel<JP, true>), dim3(G), dim3(64), lds, s, v, cam, centers, valid, cubes, grids, g, ptiles, vgrid);
-        else hipLaunchKernelGGL((unproject_persist_kernel<JP, false>), dim3(G), dim3(64), lds, s, v, cam, centers, valid, cubes, grids, g, ptiles, vgrid);
-        return SP3D_OK;
-    }
     if (variant & 8) {
         const int nw = (variant & 16) ? 1 : 4;
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
@@ -1065,21 +817,6 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
             } else {
                 return SP3D_EUNSUPPORTED;
             }
-        }
-        if ((variant & 256) && nw == 1 && !out_cl) {  // A/B: rotating two-buffer tap pipeline
-            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 4, false, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 4, false, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            return SP3D_OK;
-        }
-        if ((variant & 128) && nw == 1 && !out_cl) {  // A/B: raised wave priority while issuing the tap loads
-            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 4, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 4, true>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            return SP3D_OK;
-        }
-        if ((variant & 32) && nw == 1 && !out_cl) {   // A/B: two voxel slots in flight, more waves per SIMD
-            if (xcd) hipLaunchKernelGGL((unproject_pipe_kernel<JP, true, 1, false, float, float, 2>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            else hipLaunchKernelGGL((unproject_pipe_kernel<JP, false, 1, false, float, float, 2>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal);
-            return SP3D_OK;
         }
         if (out_cl) {
             if (nw == 1) { if (xcd) SP3D_PIPE(true, 1, true); else SP3D_PIPE(false, 1, true); }
