@@ -13,6 +13,9 @@ int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float
                                const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w,
                                int X, int Y, int Z, const float *grid_size, int W_in, int H_in, int variant,
                                void *stream);
+/* per-wave s_memtime timeline of the pipelined kernel (18 uint64 per wave: start, after P1(0), after each
+ * view, ..., [17] = number of cameras seeing the lane-0 voxel); NULL switches it off (tools/wave_timeline.py) */
+int sp3d_debug_set_timeline(void *dev_buffer);
 #ifdef __cplusplus
 }
 #endif

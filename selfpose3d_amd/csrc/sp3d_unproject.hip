@@ -22,6 +22,10 @@
 
 namespace sp3d {
 
+// measurement only (tools/wave_timeline.py): when non-null the pipelined kernel stores s_memtime stamps
+// per wave: [start, after P1(0), after view 0..V-1, end] (18 slots per wave)
+__device__ unsigned long long *g_timeline = nullptr;
+
 constexpr int TILE = 256; // voxels per workgroup (= threads per workgroup)
 
 // ------------------------------------------------------------------------------------------
@@ -427,9 +431,13 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
+    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)blockIdx.x * NW + wave) * 18 : nullptr;
+    if (tl && lane == 0) tl[0] = __builtin_readcyclecounter();
     bool have = P1(0);
+    if (tl && lane == 0) tl[1] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int c = 0; c < g.V; ++c) {
+        if (tl && lane == 0 && c > 0) tl[1 + c] = __builtin_readcyclecounter();
         const bool cur = have;
         const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
         const int rb = (c & 1) * 320 + g16;
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
+    if (tl && lane == 0) { tl[1 + g.V] = __builtin_readcyclecounter(); tl[17] = (unsigned long long)__popc(mymask); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t m = (uint32_t)__shfl((int)mymask, 16 * i + g16);
@@ -1073,4 +1082,11 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
     default: hipLaunchKernelGGL((unproject_bwd2_kernel<16, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
     }
     return launch_status();
+}
+
+// measurement only: set / clear the per-wave timeline buffer of the pipelined kernel
+extern "C" int sp3d_debug_set_timeline(void *dev_buffer)
+{
+    unsigned long long *p = (unsigned long long *)dev_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof(p));
 }
