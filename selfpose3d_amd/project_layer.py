@@ -12,7 +12,7 @@ tensors must live on the GPU and libsp3d.so must be built, otherwise this raises
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch
