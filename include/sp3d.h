@@ -181,6 +181,20 @@ int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *gri
 int sp3d_channel_shift_act(float *y, const float *shift, const float *residual, int mode, int64_t batch, int C,
                            int64_t inner, int channels_last, void *stream);
 
+/*
+ * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
+ *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D
+ *                                       Gaussian); gx/gy/gz are the fp32 voxel-centre coordinates per axis
+ *   sp3d_render_root_heatmaps :205-227  out (V,B,1,h,w) = clip(sum over roots of sigma-3 Gaussians at the roots'
+ *                                       projections); cam is the (B,V,32) table whose affine is meta['trans'],
+ *                                       stride = network-input px per heat-map px (the reference's 4.0)
+ * roots (B,R,3) fp32 mm, R <= SP3D_MAX_TOPK.  The additive N(0,0.02) noise stays with the caller.
+ */
+int sp3d_gaussian_target_3d(const float *roots, int B, int R, const float *gx, const float *gy, const float *gz, int X,
+                            int Y, int Z, float sigma, float *target, void *stream);
+int sp3d_render_root_heatmaps(const float *roots, int B, int R, const float *cam, int V, int h, int w, float stride,
+                              float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

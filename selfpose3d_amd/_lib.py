@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps",
 ]
 
 _lib = None
@@ -74,6 +74,10 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_gaussian_target_3d.restype = I
+    lib.sp3d_gaussian_target_3d.argtypes = [P, I, I, P, P, P, I, I, I, F, P, V]
+    lib.sp3d_render_root_heatmaps.restype = I
+    lib.sp3d_render_root_heatmaps.argtypes = [P, I, I, P, I, I, I, F, P, V]
     lib.sp3d_soft_argmax_grid.restype = I
     lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
     lib.sp3d_channel_shift_act.restype = I
@@ -284,3 +288,29 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
                                        _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
     check(rc, "sp3d_unproject_bwd_packed")
     return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
+
+
+def gaussian_target_3d(roots: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor, gz: torch.Tensor, sigma: float):
+    """roots (B,R,3), per-axis voxel centres -> (B,X,Y,Z) max-of-Gaussians target"""
+    lib = load()
+    _require_cuda(roots, "roots")
+    B, R = roots.shape[:2]
+    X, Y, Z = gx.numel(), gy.numel(), gz.numel()
+    r = roots.contiguous().float()
+    out = torch.empty((B, X, Y, Z), dtype=torch.float32, device=roots.device)
+    check(lib.sp3d_gaussian_target_3d(r.data_ptr(), B, R, gx.data_ptr(), gy.data_ptr(), gz.data_ptr(), X, Y, Z, float(sigma),
+                                      out.data_ptr(), _stream(roots.device)), "sp3d_gaussian_target_3d")
+    return out
+
+
+def render_root_heatmaps(roots: torch.Tensor, cam: torch.Tensor, h: int, w: int, stride: float):
+    """roots (B,R,3), cam (B,V,32) -> (V,B,1,h,w) clipped sum of sigma-3 Gaussians at the projected roots"""
+    lib = load()
+    _require_cuda(roots, "roots")
+    B, R = roots.shape[:2]
+    V = cam.shape[1]
+    r = roots.contiguous().float()
+    out = torch.empty((V, B, 1, h, w), dtype=torch.float32, device=roots.device)
+    check(lib.sp3d_render_root_heatmaps(r.data_ptr(), B, R, cam.data_ptr(), V, h, w, float(stride), out.data_ptr(),
+                                        _stream(roots.device)), "sp3d_render_root_heatmaps")
+    return out

@@ -96,6 +96,9 @@ class CuboidProposalNetSoft(nn.Module):
         the searchsorted windows of :171-199 (grid point g is inside iff mu-3s <= g <= mu+3s), clipped."""
         s = self.cur_sigma
         gx, gy, gz = self.grid1Dx, self.grid1Dy, self.grid1Dz
+        if roots.is_cuda:
+            from . import _lib
+            return _lib.gaussian_target_3d(roots, gx, gy, gz, s)
         mu = roots[:, :, None, None, None, :]                                    # (B,R,1,1,1,3)
         dx = gx.view(1, 1, -1, 1, 1) - mu[..., 0]
         dy = gy.view(1, 1, 1, -1, 1) - mu[..., 1]
@@ -111,6 +114,8 @@ class CuboidProposalNetSoft(nn.Module):
         i.e. NO r^2 clamp, then the crop affine ``meta[0]['trans']``).  -> list[V] of (B,1,h,w)."""
         dev = roots.device
         B = roots.shape[0]
+        if roots.is_cuda:
+            return self._render_hip(roots, meta, generator)
         ys = torch.arange(self.hm_h, device=dev, dtype=torch.float32).view(1, 1, -1, 1)
         xs = torch.arange(self.hm_w, device=dev, dtype=torch.float32).view(1, 1, 1, -1)
         trans = meta[0].get("trans")
@@ -145,6 +150,26 @@ class CuboidProposalNetSoft(nn.Module):
                       if generator is not None else hm + self.noise_std * torch.randn_like(hm)).clamp_(0, 1)
             out.append(hm)
         return out
+
+    @torch.no_grad()
+    def _render_hip(self, roots, meta, generator=None):
+        """GPU path of render_root_heatmaps: one launch for all views (sp3d_render_root_heatmaps)"""
+        from . import _lib
+        from .camera_pack import CAM_A, pack_cameras
+        B = roots.shape[0]
+        tab = pack_cameras(meta, B, self.project_layer.img_size)
+        trans = meta[0].get("trans")
+        if trans is not None:                      # the reference applies meta[0]['trans'] to every view (:208)
+            tab[:, :, CAM_A:CAM_A + 6] = trans.detach().cpu().numpy().reshape(B, 1, 6).astype(np.float32)
+        else:
+            tab[:, :, CAM_A:CAM_A + 6] = tab[:, :1, CAM_A:CAM_A + 6]
+        cam = torch.from_numpy(tab).to(roots.device)
+        hm = _lib.render_root_heatmaps(roots, cam, self.hm_h, self.hm_w, self.stride)
+        if self.noise_std > 0:
+            noise = torch.randn(hm.shape, generator=generator, device="cpu").to(hm.device) if generator is not None \
+                else torch.randn_like(hm)
+            hm = (hm + self.noise_std * noise).clamp_(0, 1)
+        return list(hm.unbind(0))
 
     def train_rootnet(self, batch_size, meta, pred_hms=None, flip_xcoords=None, generator=None):
         dev = self.grid1Dx.device

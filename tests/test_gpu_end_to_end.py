@@ -122,3 +122,40 @@ def test_hip_graph_replay_matches_eager_and_tracks_new_inputs():
     # new calibration (different crop scale) reaches the kernels through the pinned camera table
     out2 = g(meta2)
     assert torch.equal(out2[0], ref_c[0]) and torch.equal(out2[1], ref_c[1]) and not torch.equal(out2[0], ref_b[0])
+
+
+@pytest.mark.gpu
+def test_synthetic_root_branch_kernels_match_reference_golden_and_torch_path():
+    """sp3d_gaussian_target_3d / sp3d_render_root_heatmaps (§8 f3/f4) against the reference golden (fixed roots,
+    no noise) and, for a B=3 random batch with per-sample crops, against the vectorised torch path on the CPU."""
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net_soft import CuboidProposalNetSoft
+    from tests import golden_io as gio
+    g = gio.load("rootnet_soft_synth")
+    cfg = load_config(None, NETWORK__ROOTNET_ROOTHM=True, NETWORK__ROOTNET_TRAIN_SYNTH=True)
+    cpu = CuboidProposalNetSoft(cfg)
+    gpu = CuboidProposalNetSoft(cfg).to("cuda")
+    cpu.noise_std = gpu.noise_std = 0.0
+    u, uz, zn, lo, hi = g["u"], float(g["uz"]), g["zn"], g["lo"], g["hi"]
+    x = (hi[0] - lo[0]) * torch.from_numpy(u[..., 0:1]) + lo[0]
+    y = (hi[1] - lo[1]) * torch.from_numpy(u[..., 1:2]) + lo[1]
+    z = ((hi[2] - lo[2]) * torch.full((1, 1, 1), uz) + lo[2]).expand(1, int(g["R"]), 1) + torch.from_numpy(zn) * 50
+    roots = torch.cat([x, y, z], -1).float()
+    target = gpu.target_cubes(roots.cuda()).cpu()
+    assert float((target - torch.from_numpy(g["target"])).abs().max()) <= 1e-6
+    meta = syn.make_meta(1, 5, (960, 512), ssv_style=True)
+    meta[0]["trans"] = torch.from_numpy(g["trans"])
+    hms = gpu.render_root_heatmaps(roots.cuda(), meta)
+    for v in range(5):
+        assert hms[v].shape == (1, 1, 128, 240)
+        assert float((hms[v][0].cpu() - torch.from_numpy(g["hms"][v][0])).abs().max()) <= 2e-5
+    # B=3, rotated / rescaled crops, no meta['trans'] (derived from centre/scale/rotation)
+    meta3 = syn.make_meta(3, 5, (960, 512), rotations=[0.0, 20.0, -35.0], scale_mults=[1.0, 0.8, 1.2])
+    r3 = cpu.sample_roots(3, "cpu", torch.Generator().manual_seed(4))
+    t_c, t_g = cpu.target_cubes(r3), gpu.target_cubes(r3.cuda()).cpu()
+    assert float((t_c - t_g).abs().max()) <= 1e-6
+    h_c, h_g = cpu.render_root_heatmaps(r3, meta3), gpu.render_root_heatmaps(r3.cuda(), meta3)
+    for a, b in zip(h_c, h_g):
+        assert float((a - b.cpu()).abs().max()) <= 2e-5
+    assert float(t_g.max()) > 0.5 and float(h_g[0].max()) > 0.0
