@@ -29,6 +29,12 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(out: str, extra_flags=()) -> str:
+    """measurement builds (e.g. -DSP3D_TIMELINE for tools/wave_timeline.py); never loaded by the package"""
+    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out])
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB

@@ -24,7 +24,12 @@ namespace sp3d {
 
 // measurement only (tools/wave_timeline.py): when non-null the pipelined kernel stores s_memtime stamps
 // per wave: [start, after P1(0), after view 0..V-1, end] (18 slots per wave)
+#ifdef SP3D_TIMELINE
 __device__ unsigned long long *g_timeline = nullptr;
+#define SP3D_STAMP(slot) do { if (tl && lane == 0) tl[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SP3D_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int TILE = 256; // voxels per workgroup (= threads per workgroup)
 
@@ -328,13 +333,23 @@ struct Rec {
     float w00, w10, w01, w11;
 };
 
-template <int JP>
+// ESZ: the record's offset is in units of 1/ESZ elements (ESZ = sizeof(element) gives byte offsets)
+template <int JP, int ESZ = 1>
 __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, int h)
 {
     Rec r;
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const float wx = ix - fx0, ex = 1.0f - wx, ny = iy - fy0, sy = 1.0f - ny;
     const int x0 = (int)fx0, y0 = (int)fy0;
+    // does any used voxel of the wave have a tap in the zero padding (x0 == -1 | w-1, y0 == -1 | h-1)?
+    const bool edge = use && (((unsigned)x0 > (unsigned)(w - 2)) || ((unsigned)y0 > (unsigned)(h - 2)));
+    if (!__any(edge)) {
+        // common case: all four taps in range; voxels not seen by this camera get zero x-weights at offset 0
+        const float fxl = use ? ex : 0.0f, fxr = use ? wx : 0.0f;
+        r.w00 = sy * fxl; r.w10 = sy * fxr; r.w01 = ny * fxl; r.w11 = ny * fxr;
+        r.off = use ? (y0 * w + x0) * (JP * ESZ) : 0;
+        return r;
+    }
     // clamp the 2x2 block inside the image; d = shift of the block relative to the true taps:
     //   0: both taps in range; +1: only the right/bottom tap (x0 == -1), it now sits in the
     //   left/top slot; -1: only the left/top tap (x0 == w-1), now in the right/bottom slot;
@@ -346,7 +361,7 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
     const float fyt = dys == 0 ? sy : (dys == 1 ? ny : 0.0f);
     const float fyb = dys == 0 ? ny : (dys == -1 ? sy : 0.0f);
     r.w00 = fyt * fxl; r.w10 = fyt * fxr; r.w01 = fyb * fxl; r.w11 = fyb * fxr;
-    r.off = (y0c * w + x0c) * JP;
+    r.off = (y0c * w + x0c) * (JP * ESZ);
     return r;
 }
 
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         if (isnan && inb) mymask |= 0x80000000u;
         const bool use = bound && !isnan;
         if (!__any(use)) return false;          // no voxel of this wave sees camera c
-        const Rec r = make_record<JP>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
+        const Rec r = make_record<JP, (int)sizeof(TI)>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
         const int base = (c & 1) * 320 + lane;
         wsi[base] = r.off;
         ws[base + 64] = r.w00; ws[base + 128] = r.w10; ws[base + 192] = r.w01; ws[base + 256] = r.w11;
@@ -426,20 +441,26 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     // gather mapping
     const int g16 = lane >> 2, q = lane & 3;
     const bool qact = q < NQ;
+    const uint32_t qoff = qact ? 4u * (uint32_t)sizeof(TI) * (uint32_t)q : 0u;      // this lane's channel quad, bytes
     const size_t rowf = (size_t)g.w * JP;
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
-    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)blockIdx.x * NW + wave) * 18 : nullptr;
-    if (tl && lane == 0) tl[0] = __builtin_readcyclecounter();
+#ifdef SP3D_TIMELINE
+    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)blockIdx.x * NW + wave) * 32 : nullptr;
+#endif
+    SP3D_STAMP(0);
     bool have = P1(0);
-    if (tl && lane == 0) tl[1] = __builtin_readcyclecounter();
+    SP3D_STAMP(1);
 #pragma unroll 1
     for (int c = 0; c < g.V; ++c) {
-        if (tl && lane == 0 && c > 0) tl[1 + c] = __builtin_readcyclecounter();
+        SP3D_STAMP(2 + 4 * (c < 7 ? c : 6));
         const bool cur = have;
-        const TI *vb = reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf + (qact ? 4 * q : 0);
+        // wave-uniform row bases (SGPR pairs) + one 32-bit element offset per lane: the four taps of a slot are
+        // {vb, vb2} + off (+ JP as an immediate), no 64-bit VALU address arithmetic
+        const char *vb = reinterpret_cast<const char *>(reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf);
+        const char *vb2 = vb + rowf * sizeof(TI);
         const int rb = (c & 1) * 320 + g16;
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -453,17 +474,19 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
             if (cur) {
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    const TI *p = vb + wsi[rb + 16 * (gi * U + k)];
-                    t00[k] = Store4<TI>::load(p);
-                    t10[k] = Store4<TI>::load(p + JP);
-                    t01[k] = Store4<TI>::load(p + rowf);
-                    t11[k] = Store4<TI>::load(p + rowf + JP);
+                    const uint32_t off = (uint32_t)wsi[rb + 16 * (gi * U + k)] + qoff;      // bytes
+                    t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
+                    t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
+                    t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
+                    t11[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off) + JP);
                 }
             }
             if (gi == 0) {
                 __builtin_amdgcn_sched_barrier(0);
+                SP3D_STAMP(3 + 4 * (c < 7 ? c : 6));     // all tap loads issued
                 if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
                 __builtin_amdgcn_sched_barrier(0);
+                SP3D_STAMP(4 + 4 * (c < 7 ? c : 6));     // next view projected
             }
             if (cur) {
 #pragma unroll
@@ -481,15 +504,21 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         }
     }
 
+
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
-    if (tl && lane == 0) { tl[1 + g.V] = __builtin_readcyclecounter(); tl[17] = (unsigned long long)__popc(mymask); }
+    SP3D_STAMP(30);
+#ifdef SP3D_TIMELINE
+    if (tl && lane == 0) tl[31] = (unsigned long long)__popc(mymask);
+#endif
+    // per voxel (P1 mapping, once): den = #views seeing it + 1e-6, rden = RN(1/den), 0 for a NaN sample position
+    const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+    const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t m = (uint32_t)__shfl((int)mymask, 16 * i + g16);
-        const bool bad = (m & 0x80000000u) != 0;              // NaN sample position: voxel is zero
-        const float den = (float)__popc(m & 0x7fffffffu) + 1e-6f;
-        const float rden = bad ? 0.0f : 1.0f / den;           // rden = 0 makes fuse_rcp return exactly 0
+        const float den = __shfl(den_l, 16 * i + g16);
+        const float rden = __shfl(rden_l, 16 * i + g16);      // rden = 0 makes fuse_rcp return exactly 0
+        const bool bad = rden == 0.0f;                        // NaN sample position: voxel is zero
         if (g.pass_mask) {
             // gradient pass mask (torch.clamp backward: 0 <= pre <= 1; NaN-zeroed voxels block it)
             uint32_t bits = 0;
@@ -1087,6 +1116,11 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
 // measurement only: set / clear the per-wave timeline buffer of the pipelined kernel
 extern "C" int sp3d_debug_set_timeline(void *dev_buffer)
 {
+#ifdef SP3D_TIMELINE
     unsigned long long *p = (unsigned long long *)dev_buffer;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof(p));
+#else
+    (void)dev_buffer;
+    return SP3D_EUNSUPPORTED;       // the shipped library carries no stamps; tools/wave_timeline.py builds its own
+#endif
 }

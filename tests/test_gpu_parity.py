@@ -527,3 +527,37 @@ def test_unproject_bwd_packed_line_coalesced(dev, name):
     for j in range(case.J):
         inside = (o[:, j] > 0) & (o[:, j] < 1)
         assert np.all(((m >> j) & 1)[inside] == 1)
+
+
+@pytest.mark.parametrize("layout", ["planar", "nhwc"])
+def test_registered_torch_op_forward_and_autograd(dev, layout):
+    """torch.ops.selfpose3d_mi.unproject_fwd/bwd: same bits as the oracle, gradients = reference
+    autograd golden, for the stacked planar (V,B,J,h,w) and the channels-last (V,B,h,w,16) input forms."""
+    import selfpose3d_amd.torch_ops  # noqa: F401  (registers the ops)
+    from selfpose3d_amd import _lib
+    case = gio.Case("unproj_grad_fine_aug")
+    g = case.g
+    hms = [h.to(dev) for h in case.hms]
+    if layout == "planar":
+        hm = torch.stack(hms, 0)
+    else:
+        hm = _lib.pack_heatmaps(hms, jp=16)
+    hm = hm.clone().requires_grad_(True)
+    cam = torch.from_numpy(case.cam).to(dev)
+    centers = torch.from_numpy(case.centers).to(dev)
+    valid = torch.from_numpy(case.valid).to(dev)
+    cubes, grids = torch.ops.selfpose3d_mi.unproject_fwd(hm, cam, centers, valid, [float(v) for v in case.grid_size],
+                                                         list(case.cube), list(case.img), list(case.hm), case.J)
+    o_c, o_g = _oracle_fwd(case)
+    assert np.array_equal(cubes.detach().cpu().numpy().reshape(o_c.shape), o_c)
+    assert np.array_equal(grids.cpu().numpy(), o_g) and not grids.requires_grad
+    wgt = torch.from_numpy(np.random.default_rng(int(g["grad_seed"])).standard_normal(
+        tuple(cubes.shape)).astype(np.float32)).to(dev)
+    (cubes * wgt).sum().backward()
+    assert hm.grad.shape == hm.shape
+    for c in range(case.V):
+        got = hm.grad[c] if layout == "planar" else hm.grad[c][..., :case.J].permute(0, 3, 1, 2)
+        scale = max(1.0, float(np.abs(g["grad_hm"][c]).max()))
+        assert np.abs(got.cpu().numpy() - g["grad_hm"][c]).max() <= 2e-5 * scale
+    if layout == "nhwc":
+        assert float(hm.grad[..., case.J:].abs().max()) == 0.0

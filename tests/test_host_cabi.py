@@ -191,3 +191,26 @@ def test_rootnet_soft_synthetic_branch_matches_reference_golden():
     # per-GPU batch > 1 works here (the reference is limited to 1)
     r2 = net.sample_roots(3, "cpu", torch.Generator().manual_seed(1))
     assert r2.shape[0] == 3 and net.target_cubes(r2).shape == (3, 80, 80, 20)
+
+
+def test_torch_op_registry_face():
+    """torch.ops.selfpose3d_mi.* exist with the §8(b) schema, infer shapes under FakeTensorMode and refuse CPU tensors
+    loudly (the product has no CPU implementation)."""
+    import selfpose3d_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    fwd = torch.ops.selfpose3d_mi.unproject_fwd
+    schema = str(fwd.default._schema)
+    for arg in ("Tensor hm", "Tensor cam", "Tensor centers", "Tensor valid", "float[] grid_size", "cube_size",
+                "img_size", "hm_size"):
+        assert arg in schema, schema
+    assert "-> (Tensor, Tensor)" in schema
+    assert "Tensor grad_cubes" in str(torch.ops.selfpose3d_mi.unproject_bwd.default._schema)
+    args = lambda hm: (hm, torch.zeros(1, 2, 32), torch.zeros(1, 3), torch.ones(1, dtype=torch.uint8),
+                       [100.0, 100.0, 100.0], [4, 4, 8], [48, 32], [12, 8])
+    with pytest.raises(NotImplementedError):
+        fwd(*args(torch.zeros(2, 1, 8, 12, 16)), 15)
+    with FakeTensorMode():
+        a, b = fwd(*args(torch.zeros(2, 1, 8, 12, 16)), 15)
+        assert tuple(a.shape) == (1, 15, 4, 4, 8) and tuple(b.shape) == (1, 128, 3)
+        a, b = fwd(*args(torch.zeros(2, 1, 15, 8, 12)))
+        assert tuple(a.shape) == (1, 15, 4, 4, 8)
