@@ -24,11 +24,17 @@ namespace sp3d {
 
 // measurement only (tools/wave_timeline.py): when non-null the pipelined kernel stores s_memtime stamps
 // per wave: [start, after P1(0), after view 0..V-1, end] (18 slots per wave)
-#ifdef SP3D_TIMELINE
+#ifdef SP3D_TIMELINE        // 1: wave start / end only (light), 2: + per-view stamps
 __device__ unsigned long long *g_timeline = nullptr;
-#define SP3D_STAMP(slot) do { if (tl && lane == 0) tl[slot] = __builtin_readcyclecounter(); } while (0)
+#define SP3D_STAMP_ALWAYS(slot) do { if (tl && lane == 0) tl[slot] = __builtin_readcyclecounter(); } while (0)
+#if SP3D_TIMELINE >= 2
+#define SP3D_STAMP(slot) SP3D_STAMP_ALWAYS(slot)
 #else
 #define SP3D_STAMP(slot) do { } while (0)
+#endif
+#else
+#define SP3D_STAMP(slot) do { } while (0)
+#define SP3D_STAMP_ALWAYS(slot) do { } while (0)
 #endif
 
 constexpr int TILE = 256; // voxels per workgroup (= threads per workgroup)
@@ -365,28 +371,16 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
     return r;
 }
 
-// NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
-// TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
-template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
-                                                             const float *__restrict__ centers,
-                                                             const uint8_t *__restrict__ valid,
-                                                             float *__restrict__ cubes, float *__restrict__ grids,
-                                                             Geom g, int tiles_per_sample, int total_tiles)
+template <int JP, int NW, bool OUTCL, typename TI, typename TO, int U = 4>
+__device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restrict__ cam, const float *__restrict__ centers,
+                                          const uint8_t *__restrict__ valid, float *__restrict__ cubes,
+                                          float *__restrict__ grids, const Geom &g, int b, int tile, float *smem,
+                                          unsigned wid)
 {
     constexpr int NQ = JP / 4;
-    constexpr int U = 4;                      // voxel slots gathered per batch of loads (2 and 1 measured equal)
+    // U = voxel slots gathered per batch of loads (4, 2 and 1 measured equal in the one-tile-per-wave kernel)
     constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
-    __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
-
-    int b, tile;
-    if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
-    } else {
-        b = blockIdx.x / tiles_per_sample;
-        tile = blockIdx.x - b * tiles_per_sample;
-    }
-    (void)total_tiles;
+    (void)wid;
     const int bs = g.sample_of ? g.sample_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = tile * (64 * NW) + wave * 64;                          // first voxel of this wave
@@ -448,9 +442,12 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
 #ifdef SP3D_TIMELINE
-    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)blockIdx.x * NW + wave) * 32 : nullptr;
+    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)wid * NW + wave) * 32 : nullptr;
 #endif
-    SP3D_STAMP(0);
+    SP3D_STAMP_ALWAYS(0);
+#ifdef SP3D_TIMELINE
+    if (tl && lane == 0) tl[26] = wall_clock64();       // chip-wide 100 MHz clock (cycle counters are per XCD)
+#endif
     bool have = P1(0);
     SP3D_STAMP(1);
 #pragma unroll 1
@@ -507,8 +504,13 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
-    SP3D_STAMP(30);
+    SP3D_STAMP_ALWAYS(30);
 #ifdef SP3D_TIMELINE
+    if (tl && lane == 0) {      // where it ran: HW_ID (wave/simd/cu/se) and XCC_ID
+        tl[25] = wall_clock64();                           // view loop done, epilogue starts
+        tl[28] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+        tl[29] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
+    }
     if (tl && lane == 0) tl[31] = (unsigned long long)__popc(mymask);
 #endif
     // per voxel (P1 mapping, once): den = #views seeing it + 1e-6, rden = RN(1/den), 0 for a NaN sample position
@@ -548,6 +550,12 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
             for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
         }
     }
+#ifdef SP3D_TIMELINE
+    if (OUTCL) {
+        __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0): the result stores have left the wave
+        if (tl && lane == 0) tl[27] = wall_clock64();
+    }
+#endif
     if (OUTCL) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -562,6 +570,28 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
         for (int j = 0; j < g.J; ++j)
             if (lane < nvox) Store4<TO>::store1(cb + (size_t)j * g.N + n0 + lane, ws[j * WOSTR + lane]);
     }
+}
+
+// NW = waves per workgroup (waves are independent; NW only sets the dispatch granularity)
+// TI / TO: storage type of the packed heat-maps / of the cubes (float or bf16_t); math is fp32.
+template <int JP, bool XCD, int NW, bool OUTCL, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const float *__restrict__ cam,
+                                                             const float *__restrict__ centers,
+                                                             const uint8_t *__restrict__ valid,
+                                                             float *__restrict__ cubes, float *__restrict__ grids,
+                                                             Geom g, int tiles_per_sample, int total_tiles)
+{
+    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
+    __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
+    int b, tile;
+    if (XCD) {
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
+    } else {
+        b = blockIdx.x / tiles_per_sample;
+        tile = blockIdx.x - b * tiles_per_sample;
+    }
+    (void)total_tiles;
+    pipe_tile<JP, NW, OUTCL, TI, TO>(hm, cam, centers, valid, cubes, grids, g, b, tile, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

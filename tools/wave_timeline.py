@@ -6,16 +6,18 @@ import numpy as np, torch
 from selfpose3d_amd import _lib, synthetic as syn
 from selfpose3d_amd.camera_pack import pack_cameras
 from selfpose3d_amd import build as _build
-TL = os.path.join(ROOT, "selfpose3d_amd", "libsp3d_timeline.so")      # stamped build, separate from the shipped library
+LEVEL = 1 if "--occupancy" in sys.argv else 2
+TL = os.path.join(ROOT, "selfpose3d_amd", "libsp3d_timeline%d.so" % LEVEL)      # stamped build, separate from the shipped library
 if "--build-only" in sys.argv or not os.path.exists(TL) or os.path.getmtime(TL) < os.path.getmtime(_build.LIB):
-    _build.build_variant(TL, ["-DSP3D_TIMELINE"])
+    _build.build_variant(TL, ["-DSP3D_TIMELINE=%d" % LEVEL])
     if "--build-only" in sys.argv:
         sys.exit(0)
 _lib.LIB_PATH = TL
 lib = _lib.load()
 img, (w, h), J = (960, 512), (240, 128), 15
 dev = torch.device("cuda:0")
-B, V = int(sys.argv[1]) if len(sys.argv) > 1 else 4, 5
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+B, V = int(_pos[0]) if _pos else 4, 5
 cube, gs = syn.INITIAL_CUBE_SIZE, syn.SPACE_SIZE
 meta = syn.make_meta(B, V, img)
 cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
@@ -23,7 +25,7 @@ centers = torch.tensor([syn.SPACE_CENTER] * B, dtype=torch.float32, device=dev)
 valid = torch.ones(B, dtype=torch.uint8, device=dev)
 hms = [x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=7)]
 packed = _lib.pack_heatmaps(hms, jp=16); views = [packed[c] for c in range(V)]
-run = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False)
+run = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False, channels_last=True)
 for _ in range(5): run()
 nblk = 8 * 4096
 S = 32
@@ -39,6 +41,41 @@ start, p1, end = t[:, 0], t[:, 1], t[:, 30]
 life = end - start
 span = end.max() - start.min()
 us = e0.elapsed_time(e1) * 1e3
+if LEVEL == 1:
+    xcc = (t[:, 29] & 0xf).astype(int)
+    hw = t[:, 28].astype(np.int64)
+    cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7)      # cu_id, se_id, sh_id
+    out = {"waves": int(len(t)), "kernel_us_event": round(us, 1), "xcds": {}}
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        s0, e0_ = t[m, 26].astype(np.float64) * 10.0, t[m, 27].astype(np.float64) * 10.0      # ns
+        t0, t1 = s0.min(), e0_.max()
+        grid = np.linspace(t0, t1, 21)
+        live = [int(((s0 <= g) & (e0_ > g)).sum()) for g in grid[:-1]]
+        ncu = len(set(cu[m].tolist()))
+        out["xcds"][int(x)] = {"waves": int(m.sum()), "cus_seen": ncu, "span_us": round((t1 - t0) / 1e3, 2), "first_start_us": round((t0 - t[:, 26].min() * 10.0) / 1e3, 2),
+                               "wave_life_us": round(float((e0_ - s0).mean()) / 1e3, 2),
+                               "last_start_frac": round(float((s0.max() - t0) / (t1 - t0)), 3),
+                               "live_waves_per_cu_at_5pct_steps": [round(v / max(ncu, 1), 1) for v in live]}
+        st_ = np.sort(s0); en_ = np.sort(e0_); tg = t[:, 26].min() * 10.0
+        out["xcds"][int(x)]["epilogue_us_mean"] = round(float((t[m, 27] - t[m, 25]).mean()) * 10.0 / 1e3, 2)
+        out["xcds"][int(x)]["first_end_us"] = round(float(en_[0] - tg) / 1e3, 2)
+        out["xcds"][int(x)]["end_q10_us"] = round(float(en_[len(en_) // 10] - tg) / 1e3, 2)
+        out["xcds"][int(x)]["gen2_first_start_us"] = round(float(st_[min(512, len(st_) - 1)] - tg) / 1e3, 2)
+        if x == 0:      # per-CU / per-SE spread inside one XCD at the same instants
+            cus = sorted(set(cu[m].tolist())); cum = cu[m]; se = (cum >> 4) & 7
+            rows = []
+            for g in grid[1:-1:2]:
+                alive = (s0 <= g) & (e0_ > g)
+                per = np.array([int((alive & (cum == c_)).sum()) for c_ in cus])
+                per_se = [round(float(alive[se == k].sum()) / max(1, len(set(cum[se == k].tolist()))), 1) for k in sorted(set(se.tolist()))]
+                rows.append({"t_frac": round(float((g - t0) / (t1 - t0)), 2), "cu_min": int(per.min()), "cu_mean": round(float(per.mean()), 1),
+                             "cu_max": int(per.max()), "per_se": per_se})
+            out["xcd0_per_cu"] = rows
+            st = np.sort(s0 - t0) / 1e3
+            out["xcd0_start_us_quantiles"] = [round(float(st[int(q * (len(st) - 1))]), 2) for q in (0, .1, .25, .5, .51, .55, .6, .7, .8, .9, 1.0)]
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 # stamps per view c: [2+4c] view start, [3+4c] tap loads issued, [4+4c] P1(c+1) done; next view start = FMAs done
 nxt = lambda c: t[:, 2 + 4 * (c + 1)] if c + 1 < V else end
 res = {"waves": int(len(t)), "kernel_us_event": round(us, 1), "kernel_span_ticks": int(span), "ticks_per_us": round(span / us, 1),
