@@ -266,9 +266,11 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f)       // round to neare
 template <typename T> struct Store4;
 template <> struct Store4<float> {
     __device__ __forceinline__ static float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-    // results are written once and read by a later kernel: non-temporal stores keep them from evicting the
-    // heat-map lines the gather re-uses out of the XCD's L2 (-2.5 % on the bench workload, -8 % when the maps fit)
-    __device__ __forceinline__ static void store(float *p, float4 v)
+    __device__ __forceinline__ static void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    // the cubes are written once and read by a later kernel: non-temporal stores keep them from evicting the
+    // heat-map lines the gather re-uses out of the XCD's L2 (-2.5 % on the bench workload, -8 % when the maps fit).
+    // Not for the packed heat-maps: those are re-read by the very next kernel and should stay cached.
+    __device__ __forceinline__ static void store_nt(float *p, float4 v)
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -283,12 +285,18 @@ template <> struct Store4<bf16_t> {
         return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                            __uint_as_float(r.y & 0xffff0000u));
     }
-    __device__ __forceinline__ static void store(bf16_t *p, float4 v)
+    __device__ __forceinline__ static uint2 pack4(float4 v)
     {
         uint2 r;
         r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
         r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        return r;
+    }
+    __device__ __forceinline__ static void store(bf16_t *p, float4 v) { *reinterpret_cast<uint2 *>(p) = pack4(v); }
+    __device__ __forceinline__ static void store_nt(bf16_t *p, float4 v)
+    {
         typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+        const uint2 r = pack4(v);
         v2u t; t.x = r.x; t.y = r.y;
         __builtin_nontemporal_store(t, reinterpret_cast<v2u *>(p));
     }

@@ -543,7 +543,7 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
                 float4 o;
                 o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
                 o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                Store4<TO>::store(cb + (size_t)(n0 + nn) * g.J + 4 * q, o);
+                Store4<TO>::store_nt(cb + (size_t)(n0 + nn) * g.J + 4 * q, o);
             }
         } else if (qact) {
 #pragma unroll
@@ -564,7 +564,7 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
         for (int j = lane >> 4; j < g.J; j += 4) {
             const int u = lane & 15;
             const float4 o = *reinterpret_cast<const float4 *>(&ws[j * WOSTR + 4 * u]);
-            Store4<TO>::store(cb + (size_t)j * g.N + n0 + 4 * u, o);
+            Store4<TO>::store_nt(cb + (size_t)j * g.N + n0 + 4 * u, o);
         }
     } else {
         for (int j = 0; j < g.J; ++j)
