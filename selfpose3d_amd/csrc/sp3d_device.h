@@ -184,6 +184,15 @@ __device__ __forceinline__ bool proj_b(const float *__restrict__ cm, float y0, f
     return bound;
 }
 
+// all six entries of the crop affine finite?  (wave-uniform: integer tests on the scalar unit)
+__device__ __forceinline__ bool affine_finite(const float *__restrict__ cm)
+{
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ok = ok && ((__float_as_uint(cm[SP3D_CAM_A + i]) & 0x7f800000u) != 0x7f800000u);
+    return ok;
+}
+
 __device__ __forceinline__ void proj_c(const float *__restrict__ cm, const Geom &g, float px, float py, float &ix,
                                        float &iy, bool &isnan)
 {
@@ -191,10 +200,16 @@ __device__ __forceinline__ void proj_c(const float *__restrict__ cm, const Geom 
     const float qy = fmaf(cm[SP3D_CAM_A + 5], 1.0f, fmaf(cm[SP3D_CAM_A + 4], py, cm[SP3D_CAM_A + 3] * px));
     const float W_in = (float)g.W_in, H_in = (float)g.H_in;
     if (cm[SP3D_CAM_FLIP] != 0.0f) qx = W_in - qx;
-    const float ux = div_const(qx * (float)g.w, W_in, g.rW_in);
-    const float uy = div_const(qy * (float)g.h, H_in, g.rH_in);
-    float gx = div_const(ux, (float)(g.w - 1), g.rw1) * 2.0f - 1.0f;
-    float gy = div_const(uy, (float)(g.h - 1), g.rh1) * 2.0f - 1.0f;
+    float gx, gy;
+    if (__builtin_expect(affine_finite(cm), 1)) {
+        const float ux = div_const(qx * (float)g.w, W_in, g.rW_in);
+        const float uy = div_const(qy * (float)g.h, H_in, g.rH_in);
+        gx = div_const(ux, (float)(g.w - 1), g.rw1) * 2.0f - 1.0f;
+        gy = div_const(uy, (float)(g.h - 1), g.rh1) * 2.0f - 1.0f;
+    } else {                                        // infinite q: div_const would turn it into NaN, IEEE keeps it
+        gx = qx * (float)g.w / W_in / (float)(g.w - 1) * 2.0f - 1.0f;
+        gy = qy * (float)g.h / H_in / (float)(g.h - 1) * 2.0f - 1.0f;
+    }
     isnan = isnan || (gx != gx) || (gy != gy);      // non-finite camera tables only
     gx = clamp_fast(gx, -1.1f, 1.1f);
     gy = clamp_fast(gy, -1.1f, 1.1f);

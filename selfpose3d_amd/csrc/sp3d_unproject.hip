@@ -418,11 +418,19 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
 
     auto P1 = [&](int c) -> bool {
         const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
-        float ix, iy;
+        float y0, y1, px, py, ix, iy;
         bool isnan;
-        const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
+        proj_a(cm, x, y, z, y0, y1);
+        const bool bound = proj_b(cm, y0, y1, px, py, isnan) && inb;
         if (bound) mymask |= (1u << c);
         if (isnan && inb) mymask |= 0x80000000u;
+        // nobody in this wave is inside image c: skip the crop affine .. record.  The only thing the rest could
+        // still add is a NaN born in the affine stage, which needs a non-finite affine row (checked on the scalar unit)
+        if (!__any(bound && !isnan) && affine_finite(cm)) return false;
+        bool isnan_c = false;
+        proj_c(cm, g, px, py, ix, iy, isnan_c);
+        if (isnan_c && inb) mymask |= 0x80000000u;
+        isnan = isnan || isnan_c;
         const bool use = bound && !isnan;
         if (!__any(use)) return false;          // no voxel of this wave sees camera c
         const Rec r = make_record<JP, (int)sizeof(TI)>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);

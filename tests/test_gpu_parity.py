@@ -561,3 +561,24 @@ def test_registered_torch_op_forward_and_autograd(dev, layout):
         assert np.abs(got.cpu().numpy() - g["grad_hm"][c]).max() <= 2e-5 * scale
     if layout == "nhwc":
         assert float(hm.grad[..., case.J:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("field", ["affine_inf", "affine_nan", "focal_nan"])
+def test_non_finite_camera_rows_follow_the_reference(dev, field):
+    """A non-finite camera / crop row makes every sample position of that view NaN; the reference then zeroes the
+    voxel (project_layer.py:98).  The wave-level early-outs of the HIP kernel must not hide that."""
+    from selfpose3d_amd.camera_pack import CAM_A, CAM_F
+    case = gio.Case("unproj_coarse_small")
+    cam = case.cam.copy()
+    if field == "affine_inf":
+        cam[0, 1, CAM_A] = np.inf
+    elif field == "affine_nan":
+        cam[0, 1, CAM_A + 5] = np.nan
+    else:
+        cam[0, 0, CAM_F] = np.nan
+    case.cam = cam
+    ref_c, ref_g = _oracle_fwd(case)
+    for layout in ("planar", "nhwc"):
+        cubes, grids = _hip_fwd(case, dev, layout)
+        assert np.array_equal(cubes.cpu().numpy().reshape(ref_c.shape), ref_c), layout
+    assert float(np.abs(ref_c[0]).max()) == 0.0 or field == "affine_inf"
