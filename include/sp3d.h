@@ -195,6 +195,13 @@ int sp3d_gaussian_target_3d(const float *roots, int B, int R, const float *gx, c
 int sp3d_render_root_heatmaps(const float *roots, int B, int R, const float *cam, int V, int h, int w, float stride,
                               float *out, void *stream);
 
+/*
+ * Channel contraction of a frequency-domain convolution (the 7x7x7 opening conv of V2VNet, lib/models/v2v_net.py:
+ * 113-117, run as rFFT -> this -> irFFT in inference):  Y[b,o,f] = sum_c X[b,c,f] * W[o,c,f], complex64 stored as
+ * interleaved (re,im) floats; X (B,C,F), W (O,C,F) (= conj FFT of the weights), Y (B,O,F), F = number of bins.
+ */
+int sp3d_freq_contract(const float *X, const float *W, float *Y, int B, int C, int O, int64_t F, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

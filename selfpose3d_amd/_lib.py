@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_freq_contract.restype = I
+    lib.sp3d_freq_contract.argtypes = [P, P, P, I, I, I, C.c_int64, V]
     lib.sp3d_gaussian_target_3d.restype = I
     lib.sp3d_gaussian_target_3d.argtypes = [P, I, I, P, P, P, I, I, I, F, P, V]
     lib.sp3d_render_root_heatmaps.restype = I
@@ -314,3 +316,21 @@ def render_root_heatmaps(roots: torch.Tensor, cam: torch.Tensor, h: int, w: int,
     check(lib.sp3d_render_root_heatmaps(r.data_ptr(), B, R, cam.data_ptr(), V, h, w, float(stride), out.data_ptr(),
                                         _stream(roots.device)), "sp3d_render_root_heatmaps")
     return out
+
+
+def freq_contract(Xf: torch.Tensor, Wf: torch.Tensor) -> torch.Tensor:
+    """Xf (B,C,*F) complex64, Wf (O,C,*F) complex64 (contiguous) -> Yf (B,O,*F) = sum_c Xf * Wf"""
+    lib = load()
+    _require_cuda(Xf, "Xf")
+    if Xf.dtype != torch.complex64 or Wf.dtype != torch.complex64 or Xf.shape[2:] != Wf.shape[2:] or Xf.shape[1] != Wf.shape[1]:
+        raise Sp3dError("freq_contract: complex64 (B,C,*F) x (O,C,*F) expected")
+    Xf, Wf = Xf.resolve_conj().contiguous(), Wf.resolve_conj().contiguous()      # data_ptr() ignores a lazy conj bit
+    B, Cc = int(Xf.shape[0]), int(Xf.shape[1])
+    O = int(Wf.shape[0])
+    Fn = 1
+    for d in Xf.shape[2:]:
+        Fn *= int(d)
+    Yf = torch.empty((B, O) + tuple(Xf.shape[2:]), dtype=torch.complex64, device=Xf.device)
+    check(lib.sp3d_freq_contract(Xf.data_ptr(), Wf.data_ptr(), Yf.data_ptr(), B, Cc, O, Fn, _stream(Xf.device)),
+          "sp3d_freq_contract")
+    return Yf

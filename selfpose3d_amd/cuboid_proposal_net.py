@@ -73,8 +73,9 @@ class CuboidProposalNet(nn.Module):
             hms = [a[:, self.root_id:self.root_id + 1].contiguous() for a in all_heatmaps]
         else:
             hms = all_heatmaps
+        planar = self.v2v_net.wants_planar_input() and hms[0].is_cuda      # FFT opening conv: plain J-channel cubes
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
-                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=True,
-                                                channels_last=self.channels_last)
+                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=not planar,
+                                                channels_last=self.channels_last and not planar)
         root_cubes = self.v2v_net(cubes).squeeze(1)
         return root_cubes, self.proposal_layer(root_cubes, meta)

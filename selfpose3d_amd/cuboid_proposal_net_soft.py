@@ -65,9 +65,10 @@ class CuboidProposalNetSoft(nn.Module):
 
     # -- shared: heat-maps -> root cubes ---------------------------------------------------------------
     def _root_cubes(self, hms, meta, flip_xcoords):
+        planar = self.v2v_net.wants_planar_input() and hms[0].is_cuda      # FFT opening conv: plain J-channel cubes
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
-                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=True,
-                                                channels_last=self.channels_last)
+                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=not planar,
+                                                channels_last=self.channels_last and not planar)
         return self.v2v_net(cubes).squeeze(1)
 
     def get_grid_centres(self, all_heatmaps, meta, flip_xcoords=None):

@@ -63,9 +63,10 @@ class PoseRegressionNet(nn.Module):
         bi, ki = pairs[:, 0], pairs[:, 1]
         centers = grid_centers[bi, ki, :3].contiguous()
         flip = None if flip_xcoords is None else flip_xcoords
+        planar = self.v2v_net.wants_planar_input()                       # FFT opening conv: plain J-channel cubes
         cubes, _ = self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, centers, self.cube_size,
-                                                flip_xcoords=flip, want_grids=False, pad_channels=True,
-                                                channels_last=self.channels_last, sample_of=bi)
+                                                flip_xcoords=flip, want_grids=False, pad_channels=not planar,
+                                                channels_last=self.channels_last and not planar, sample_of=bi)
         outs = []
         for s0 in range(0, P, max_cubes_per_call):
             chunk = cubes[s0:s0 + max_cubes_per_call]
@@ -76,7 +77,7 @@ class PoseRegressionNet(nn.Module):
             m = 1 << (n - 1).bit_length()
             if m != n:
                 chunk = torch.cat([chunk, chunk[-1:].expand(m - n, -1, -1, -1, -1)], 0)
-                if self.channels_last:
+                if self.channels_last and not planar:
                     chunk = chunk.contiguous(memory_format=torch.channels_last_3d)
             y = self.v2v_net(chunk)[:n]
             outs.append(_lib.soft_argmax_grid(y, cen, self.grid_size, self.cube_size, self.soft_argmax_layer.beta))
@@ -87,9 +88,10 @@ class PoseRegressionNet(nn.Module):
         B, J = all_heatmaps[0].shape[:2]
         device = all_heatmaps[0].device
         pred = torch.zeros(B, J, 3, device=device)
+        planar = self.v2v_net.wants_planar_input() and all_heatmaps[0].is_cuda
         cubes, grids = self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, grid_centers, self.cube_size,
-                                                    flip_xcoords=flip_xcoords, pad_channels=True,
-                                                    channels_last=self.channels_last)
+                                                    flip_xcoords=flip_xcoords, pad_channels=not planar,
+                                                    channels_last=self.channels_last and not planar)
         index = grid_centers[:, 3] >= 0
         if bool(index.any()):
             valid_cubes = self.v2v_net(cubes[index])
