@@ -210,8 +210,8 @@ class _FoldedV2V:
         buf[:, :, p:p + X, p:p + Y, p:p + Z].copy_(x[:, :cin])
         Yf = _lib.freq_contract(torch.fft.rfftn(buf, dim=(2, 3, 4)), self.t[wkey])
         y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[:, :, :X, :Y, :Z]
-        cl = self.net.output_layer.weight.is_contiguous(memory_format=torch.channels_last_3d) and \
-            not self.net.output_layer.weight.is_contiguous()
+        w1 = self.t["front_res"][0]             # a 3x3x3 weight tells the layout the conv stack runs in
+        cl = w1.is_contiguous(memory_format=torch.channels_last_3d) and not w1.is_contiguous()
         y = y.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
         return _lib.channel_shift_act_(y, s0, 1)
 

@@ -582,3 +582,33 @@ def test_non_finite_camera_rows_follow_the_reference(dev, field):
         cubes, grids = _hip_fwd(case, dev, layout)
         assert np.array_equal(cubes.cpu().numpy().reshape(ref_c.shape), ref_c), layout
     assert float(np.abs(ref_c[0]).max()) == 0.0 or field == "affine_inf"
+
+
+@pytest.mark.parametrize("shape", [(4, 15, 16, (12, 10, 8)), (1, 3, 5, (6, 6, 4)), (2, 16, 16, (8, 8, 8)), (7, 15, 16, (10, 6, 6))])
+def test_freq_contract_and_fft_opening_conv(dev, shape):
+    """sp3d_freq_contract == the complex einsum it replaces, and rFFT -> contraction -> irFFT == the direct 7x7x7
+    convolution it stands for (float64 as the referee: the FFT route must not be further from it than the direct
+    fp32 convolution is, plus a small margin)."""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    from selfpose3d_amd.v2v_net import _FoldedV2V
+    B, C, O, (X, Y, Z) = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.rand((B, C, X, Y, Z), generator=g).to(dev)
+    w = (torch.randn((O, C, 7, 7, 7), generator=g) * 0.05).to(dev)
+    S = tuple(_FoldedV2V._fft_len(n + 6) for n in (X, Y, Z))
+    Wf = torch.conj(torch.fft.rfftn(w, s=S, dim=(2, 3, 4))).resolve_conj().contiguous()
+    xp = F.pad(x, (3, S[2] - Z - 3, 3, S[1] - Y - 3, 3, S[0] - X - 3))
+    Xf = torch.fft.rfftn(xp, dim=(2, 3, 4))
+    Yf = _lib.freq_contract(Xf, Wf)
+    ref = torch.einsum("bcxyz,ocxyz->boxyz", Xf, Wf)
+    assert float((Yf - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    # a lazily conjugated view must be honoured (data_ptr() alone would ignore the conj bit)
+    Yf2 = _lib.freq_contract(Xf, torch.conj(torch.fft.rfftn(w, s=S, dim=(2, 3, 4))))
+    assert torch.equal(Yf2, Yf)
+    y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[..., :X, :Y, :Z]
+    ref64 = F.conv3d(x.double(), w.double(), padding=3)
+    direct = F.conv3d(x, w, padding=3)
+    err_fft = float((y.double() - ref64).abs().max())
+    err_direct = float((direct.double() - ref64).abs().max())
+    assert err_fft <= max(2.0 * err_direct, 2e-5), (err_fft, err_direct)

@@ -214,3 +214,16 @@ def test_torch_op_registry_face():
         assert tuple(a.shape) == (1, 15, 4, 4, 8) and tuple(b.shape) == (1, 128, 3)
         a, b = fwd(*args(torch.zeros(2, 1, 15, 8, 12)))
         assert tuple(a.shape) == (1, 15, 4, 4, 8)
+
+
+def test_fft_lengths_for_the_opening_conv():
+    """FFT sizes of the frequency-domain 7x7x7 conv: even, >= n + 6, prime factors <= 13"""
+    from selfpose3d_amd.v2v_net import _FoldedV2V
+    for n, want in ((86, 88), (26, 26), (70, 70), (22, 22), (14, 14), (46, 48), (134, 140)):
+        m = _FoldedV2V._fft_len(n)
+        assert m == want and m % 2 == 0 and m >= n
+        r = m
+        for q in (2, 3, 5, 7, 11, 13):
+            while r % q == 0:
+                r //= q
+        assert r == 1
