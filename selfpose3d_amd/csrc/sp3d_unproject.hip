@@ -937,7 +937,6 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
     if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;    // the clamped 2x2 block needs a 2x2 image
     if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
-    if (io) variant &= ~64;
     if (io) variant |= 16;
     int rc;
     switch (Jp) {
