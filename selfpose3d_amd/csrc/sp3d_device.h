@@ -32,6 +32,7 @@ struct Geom {
     uint32_t magicYZ, magicZ;     // floor(2^32/d)+1 for d = Y*Z, Z (exact n/d with one fix-up, see udiv_magic)
     const int *sample_of;         // optional (P): heat-map / camera row each output cube reads (NULL: identity)
     int xcd_chunk;                // tiles per chunk of the XCD-affine tile map (power of two)
+    int xcd_order;                // 0: chunks in sweep order, 1: centre of the volume first
     uint16_t *pass_mask;          // optional (P,N): bit j set iff 0 <= pre-clamp value of channel j <= 1 and the
                                   // voxel is not NaN-zeroed (where torch's clamp / index_put_ let gradient through)
 };
@@ -342,14 +343,19 @@ __host__ __device__ __forceinline__ int xcd_slots_per_xcd(int B, int tiles, int 
 }
 __host__ __device__ __forceinline__ int xcd_grid_blocks(int B, int tiles, int K) { return 8 * xcd_slots_per_xcd(B, tiles, K); }
 
-__device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int K, int &b, int &tile)
+__device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int K, int &b, int &tile, int order = 0)
 {
     const int x = bid & 7, slot = bid >> 3;
     if (B <= 8 && (8 % B) == 0) {
         const int xps = 8 / B;
         b = x / xps;
         const int sub = x - b * xps;
-        const int chunk = (slot / K) * xps + sub;
+        int row = slot / K;                                   // chunk rows in dispatch order
+        if (order == 1) {                                     // centre-out: the cheap edge-of-volume tiles run last
+            const int rows = ((tiles + K - 1) / K + xps - 1) / xps, mid = rows / 2;
+            row = mid + ((row & 1) ? -((row + 1) >> 1) : (row >> 1));
+        }
+        const int chunk = row * xps + sub;
         tile = chunk * K + (slot & (K - 1));
         return tile < tiles;
     }

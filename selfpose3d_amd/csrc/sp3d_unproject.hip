@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
     int b, tile;
     if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile)) return;
+        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile, g.xcd_order)) return;
     } else {
         b = blockIdx.x / tiles_per_sample;
         tile = blockIdx.x - b * tiles_per_sample;
@@ -811,6 +811,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.sample_of = nullptr;
     g.pass_mask = nullptr;
     g.xcd_chunk = 1;
+    g.xcd_order = 0;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
     g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
@@ -922,6 +923,7 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
                        float *cubes, float *grids, const Geom &g_in, int variant, bool out_cl, int io, hipStream_t s)
 {
     Geom g = g_in;
+    g.xcd_order = ((variant >> 21) & 1) ? 0 : 1;             // centre-out chunk order unless tuning bit 21 asks for the plain sweep
     if ((variant >> 17) & 15) {
         g.xcd_chunk = 1 << (((variant >> 17) & 15) - 1);   // tuning bits 17-20: log2(K)+1
     } else {
