@@ -201,6 +201,11 @@ int sp3d_render_root_heatmaps(const float *roots, int B, int R, const float *cam
  * interleaved (re,im) floats; X (B,C,F), W (O,C,F) (= conj FFT of the weights), Y (B,O,F), F = number of bins.
  */
 int sp3d_freq_contract(const float *X, const float *W, float *Y, int B, int C, int O, int64_t F, void *stream);
+/* general form, Y[i,j,f] = sum_k P[i,k,f] * Q[j,k,f] with optional conjugation of either operand; strides of the two
+ * leading dimensions in complex elements (bins contiguous).  Also serves the two backward products of the layer:
+ * grad input = sum_o Gy[b,o] W^[o,c], grad weight = sum_b conj(Gy[b,o]) X[b,c]  (autograd of v2v_net.py:113-117). */
+int sp3d_freq_contract_ex(const float *P, const float *Q, float *Y, int I, int J, int K, int64_t F, int64_t sPi,
+                          int64_t sPk, int64_t sQj, int64_t sQk, int conj_p, int conj_q, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_freq_contract_ex.restype = I
+    lib.sp3d_freq_contract_ex.argtypes = [P, P, P, I, I, I] + [C.c_int64] * 5 + [I, I, V]
     lib.sp3d_freq_contract.restype = I
     lib.sp3d_freq_contract.argtypes = [P, P, P, I, I, I, C.c_int64, V]
     lib.sp3d_gaussian_target_3d.restype = I
@@ -334,3 +336,39 @@ def freq_contract(Xf: torch.Tensor, Wf: torch.Tensor) -> torch.Tensor:
     check(lib.sp3d_freq_contract(Xf.data_ptr(), Wf.data_ptr(), Yf.data_ptr(), B, Cc, O, Fn, _stream(Xf.device)),
           "sp3d_freq_contract")
     return Yf
+
+
+def freq_contract_ex(Pf: torch.Tensor, Qf: torch.Tensor, mode: str) -> torch.Tensor:
+    """the three products of the frequency-domain conv on contiguous complex64 (A,B,*F) operands:
+    'fwd'  Pf = X (B,C,*F), Qf = W^ (O,C,*F)  -> (B,O,*F) = sum_c X conj(W^)
+    'dx'   Pf = Gy (B,O,*F), Qf = W^ (O,C,*F) -> (B,C,*F) = sum_o Gy W^
+    'dw'   Pf = Gy (B,O,*F), Qf = X (B,C,*F)  -> (O,C,*F) = sum_b conj(Gy) X"""
+    lib = load()
+    _require_cuda(Pf, "Pf")
+    Pf, Qf = Pf.resolve_conj().contiguous(), Qf.resolve_conj().contiguous()
+    if Pf.dtype != torch.complex64 or Qf.dtype != torch.complex64 or Pf.shape[2:] != Qf.shape[2:]:
+        raise Sp3dError("freq_contract_ex: complex64 operands with equal frequency shape expected")
+    Fn = 1
+    for d in Pf.shape[2:]:
+        Fn *= int(d)
+    p0, p1, q0, q1 = int(Pf.shape[0]), int(Pf.shape[1]), int(Qf.shape[0]), int(Qf.shape[1])
+    if mode == "fwd":       # i=b, k=c, j=o
+        I, K, J = p0, p1, q0
+        sPi, sPk, sQj, sQk, cp, cq = p1 * Fn, Fn, q1 * Fn, Fn, 0, 1
+        ok = q1 == p1
+    elif mode == "dx":      # i=b, k=o, j=c
+        I, K, J = p0, p1, q1
+        sPi, sPk, sQj, sQk, cp, cq = p1 * Fn, Fn, Fn, q1 * Fn, 0, 0
+        ok = q0 == p1
+    elif mode == "dw":      # i=o, k=b, j=c
+        I, K, J = p1, p0, q1
+        sPi, sPk, sQj, sQk, cp, cq = Fn, p1 * Fn, Fn, q1 * Fn, 1, 0
+        ok = q0 == p0
+    else:
+        raise Sp3dError(f"freq_contract_ex: unknown mode {mode}")
+    if not ok:
+        raise Sp3dError("freq_contract_ex: contracted dimensions differ")
+    Y = torch.empty((I, J) + tuple(Pf.shape[2:]), dtype=torch.complex64, device=Pf.device)
+    check(lib.sp3d_freq_contract_ex(Pf.data_ptr(), Qf.data_ptr(), Y.data_ptr(), I, J, K, Fn, sPi, sPk, sQj, sQk, cp, cq,
+                                    _stream(Pf.device)), "sp3d_freq_contract_ex")
+    return Y

@@ -17,26 +17,37 @@
 
 namespace sp3d {
 
-template <int BB, int OG>
-__global__ __launch_bounds__(256) void freq_contract_kernel(const float2 *__restrict__ X, const float2 *__restrict__ W,
-                                                           float2 *__restrict__ Y, int B, int C, int O, int64_t F)
+// Y[i, j, f] = sum_k P[i, k, f] * Q[j, k, f]   (optionally conj(P) / conj(Q)); every operand has the frequency bins
+// contiguous, its two leading dimensions at the given strides (in complex elements).  The three products of the
+// frequency-domain convolution are instances of it:
+//   forward      Y[b,o] = sum_c X[b,c] conj(W^)[o,c]          P = X, Q = W^ (conjQ)
+//   grad input   Gx[b,c] = sum_o Gy[b,o] W^[o,c]              P = Gy, Q = W^ read as [c][o]
+//   grad weight  Gw[o,c] = sum_b conj(Gy[b,o]) X[b,c]         P = Gy read as [o][b] (conjP), Q = X read as [c][b]
+template <int BB, int OG, bool CONJP, bool CONJQ>
+__global__ __launch_bounds__(256) void freq_contract_kernel(const float2 *__restrict__ P, const float2 *__restrict__ Q,
+                                                           float2 *__restrict__ Y, int I, int J, int K, int64_t F,
+                                                           int64_t sPi, int64_t sPk, int64_t sQj, int64_t sQk)
 {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
-    const int o0 = blockIdx.y * OG, b0 = blockIdx.z * BB;
+    const int j0 = blockIdx.y * OG, i0 = blockIdx.z * BB;
     float2 acc[BB][OG];
 #pragma unroll
     for (int b = 0; b < BB; ++b)
 #pragma unroll
         for (int o = 0; o < OG; ++o) acc[b][o] = make_float2(0.0f, 0.0f);
-    for (int c = 0; c < C; ++c) {
+    for (int k = 0; k < K; ++k) {
         float2 x[BB], w[OG];
 #pragma unroll
-        for (int b = 0; b < BB; ++b)
-            x[b] = (b0 + b < B) ? X[((int64_t)(b0 + b) * C + c) * F + f] : make_float2(0.0f, 0.0f);
+        for (int b = 0; b < BB; ++b) {
+            x[b] = (i0 + b < I) ? P[(int64_t)(i0 + b) * sPi + (int64_t)k * sPk + f] : make_float2(0.0f, 0.0f);
+            if (CONJP) x[b].y = -x[b].y;
+        }
 #pragma unroll
-        for (int o = 0; o < OG; ++o)
-            w[o] = (o0 + o < O) ? W[((int64_t)(o0 + o) * C + c) * F + f] : make_float2(0.0f, 0.0f);
+        for (int o = 0; o < OG; ++o) {
+            w[o] = (j0 + o < J) ? Q[(int64_t)(j0 + o) * sQj + (int64_t)k * sQk + f] : make_float2(0.0f, 0.0f);
+            if (CONJQ) w[o].y = -w[o].y;
+        }
 #pragma unroll
         for (int b = 0; b < BB; ++b)
 #pragma unroll
@@ -51,29 +62,43 @@ __global__ __launch_bounds__(256) void freq_contract_kernel(const float2 *__rest
     for (int b = 0; b < BB; ++b)
 #pragma unroll
         for (int o = 0; o < OG; ++o)
-            if (b0 + b < B && o0 + o < O) Y[((int64_t)(b0 + b) * O + (o0 + o)) * F + f] = acc[b][o];
+            if (i0 + b < I && j0 + o < J) Y[((int64_t)(i0 + b) * J + (j0 + o)) * F + f] = acc[b][o];
+}
+
+template <bool CP, bool CQ>
+static void launch_contract(const float2 *p, const float2 *q, float2 *y, int I, int J, int K, int64_t F, int64_t sPi,
+                            int64_t sPk, int64_t sQj, int64_t sQk, hipStream_t s)
+{
+    const unsigned gx = (unsigned)((F + 255) / 256);
+    if (I >= 3)
+        hipLaunchKernelGGL((freq_contract_kernel<4, 8, CP, CQ>), dim3(gx, (J + 7) / 8, (I + 3) / 4), dim3(256), 0, s, p, q, y, I, J, K, F, sPi, sPk, sQj, sQk);
+    else if (I == 2)
+        hipLaunchKernelGGL((freq_contract_kernel<2, 8, CP, CQ>), dim3(gx, (J + 7) / 8, 1), dim3(256), 0, s, p, q, y, I, J, K, F, sPi, sPk, sQj, sQk);
+    else
+        hipLaunchKernelGGL((freq_contract_kernel<1, 16, CP, CQ>), dim3(gx, (J + 15) / 16, 1), dim3(256), 0, s, p, q, y, I, J, K, F, sPi, sPk, sQj, sQk);
 }
 
 } // namespace sp3d
 
 using namespace sp3d;
 
-extern "C" int sp3d_freq_contract(const float *X, const float *W, float *Y, int B, int C, int O, int64_t F, void *stream)
+extern "C" int sp3d_freq_contract_ex(const float *P, const float *Q, float *Y, int I, int J, int K, int64_t F,
+                                     int64_t sPi, int64_t sPk, int64_t sQj, int64_t sQk, int conj_p, int conj_q,
+                                     void *stream)
 {
-    if (B <= 0 || C <= 0 || O <= 0 || F <= 0) return SP3D_EINVAL;
-    if (!X || !W || !Y) return SP3D_ENULL;
-    if ((F + 255) / 256 > 0x7fffffff || B > 65535 * 4) return SP3D_ERANGE;
-    const float2 *x = reinterpret_cast<const float2 *>(X), *w = reinterpret_cast<const float2 *>(W);
+    if (I <= 0 || J <= 0 || K <= 0 || F <= 0) return SP3D_EINVAL;
+    if (!P || !Q || !Y) return SP3D_ENULL;
+    if ((F + 255) / 256 > 0x7fffffff || I > 65535 * 4 || J > 65535 * 8) return SP3D_ERANGE;
+    const float2 *p = reinterpret_cast<const float2 *>(P), *q = reinterpret_cast<const float2 *>(Q);
     float2 *y = reinterpret_cast<float2 *>(Y);
     hipStream_t s = (hipStream_t)stream;
-    const unsigned gx = (unsigned)((F + 255) / 256);
-    if (B >= 3) {
-        hipLaunchKernelGGL((freq_contract_kernel<4, 8>), dim3(gx, (O + 7) / 8, (B + 3) / 4), dim3(256), 0, s, x, w, y, B, C, O, F);
-    } else if (B == 2) {
-        hipLaunchKernelGGL((freq_contract_kernel<2, 8>), dim3(gx, (O + 7) / 8, 1), dim3(256), 0, s, x, w, y, B, C, O, F);
-    } else {
-        hipLaunchKernelGGL((freq_contract_kernel<1, 16>), dim3(gx, (O + 15) / 16, 1), dim3(256), 0, s, x, w, y, B, C, O, F);
-    }
+    if (conj_p) { if (conj_q) launch_contract<true, true>(p, q, y, I, J, K, F, sPi, sPk, sQj, sQk, s); else launch_contract<true, false>(p, q, y, I, J, K, F, sPi, sPk, sQj, sQk, s); }
+    else { if (conj_q) launch_contract<false, true>(p, q, y, I, J, K, F, sPi, sPk, sQj, sQk, s); else launch_contract<false, false>(p, q, y, I, J, K, F, sPi, sPk, sQj, sQk, s); }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_freq_contract(const float *X, const float *W, float *Y, int B, int C, int O, int64_t F, void *stream)
+{
+    return sp3d_freq_contract_ex(X, W, Y, B, O, C, F, (int64_t)C * F, F, (int64_t)C * F, F, 0, 0, stream);
 }

@@ -19,15 +19,94 @@ def _bn(c):
     return nn.BatchNorm3d(c)
 
 
+def fft_len(n: int) -> int:
+    """smallest even m >= n whose prime factors are <= 13 (rocFFT radices)"""
+    m = n + (n & 1)
+    while True:
+        r = m
+        for q in (2, 3, 5, 7, 11, 13):
+            while r % q == 0:
+                r //= q
+        if r == 1:
+            return m
+        m += 2
+
+
+class _FreqConv3d(torch.autograd.Function):
+    """Stride-1 'same' Conv3d (odd cubic kernel) in the frequency domain, forward AND backward, for the 7x7x7 opening
+    conv of the V2V nets (v2v_net.py:113-117) on the GPU: zero-padded rFFT (rocFFT through torch.fft) -> channel
+    contraction (sp3d_freq_contract_ex) -> irFFT.  With xp = x shifted by p = k//2 into an S-sized zero volume:
+        y  = crop_[0,X)  irfft( sum_c  rfft(xp)[b,c] * conj(rfft(w)[o,c]) )
+        dx = crop_[p,p+X) irfft( sum_o  rfft(gy)[b,o] * rfft(w)[o,c] )
+        dw = crop_[0,k)  irfft( sum_b  conj(rfft(gy)[b,o]) * rfft(xp)[b,c] )
+    (cross-correlation theorem; no wrap-around because S >= X + k - 1 per axis)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        from . import _lib
+        B, C, X, Y, Z = x.shape
+        O, k = int(w.shape[0]), int(w.shape[2])
+        p = k // 2
+        S = (fft_len(X + k - 1), fft_len(Y + k - 1), fft_len(Z + k - 1))
+        xp = x.new_zeros((B, C) + S)
+        xp[:, :, p:p + X, p:p + Y, p:p + Z] = x
+        Wf = torch.fft.rfftn(w.float(), s=S, dim=(2, 3, 4))
+        Yf = _lib.freq_contract_ex(torch.fft.rfftn(xp, dim=(2, 3, 4)), Wf, "fwd")
+        y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[:, :, :X, :Y, :Z]
+        if bias is not None:
+            y = y + bias.view(1, O, 1, 1, 1)
+        cl = x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.geom = (S, p, bias is not None, cl)
+        return y.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        x, w = ctx.saved_tensors
+        S, p, has_bias, cl = ctx.geom
+        B, C, X, Y, Z = x.shape
+        O, k = int(w.shape[0]), int(w.shape[2])
+        gp = gy.new_zeros((B, O) + S)
+        gp[:, :, :X, :Y, :Z] = gy
+        Gf = torch.fft.rfftn(gp, dim=(2, 3, 4))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            Wf = torch.fft.rfftn(w.float(), s=S, dim=(2, 3, 4))
+            gx = torch.fft.irfftn(_lib.freq_contract_ex(Gf, Wf, "dx"), s=S, dim=(2, 3, 4))[:, :, p:p + X, p:p + Y, p:p + Z]
+            gx = gx.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
+        if ctx.needs_input_grad[1]:
+            xp = x.new_zeros((B, C) + S)
+            xp[:, :, p:p + X, p:p + Y, p:p + Z] = x
+            Xf = torch.fft.rfftn(xp, dim=(2, 3, 4))
+            gw = torch.fft.irfftn(_lib.freq_contract_ex(Gf, Xf, "dw"), s=S, dim=(2, 3, 4))[:, :, :k, :k, :k]
+            gw = gw.contiguous().to(w.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3, 4))
+        return gx, gw, gb
+
+
 class PadCinConv3d(nn.Conv3d):
     """Conv3d whose input-channel count is rounded up to a multiple of 4 AT RUN TIME (zero input
     channels x zero weight slices: same math, parameters and state_dict unchanged).  MIOpen's
     7^3 kernels for Cin = 15 run 3.2x slower than for Cin = 16 on gfx950 (4.84 ms vs 1.51 ms at
     (4,15,80,80,20), tools/bench_cin.py); callers may also hand in an already padded tensor."""
 
+    # 7^3 kernels on the GPU run through _FreqConv3d.  The weight spectrum (O*C volumes) has to be recomputed on every
+    # call while the weights train - and once more, plus the O*C inverse transforms of the weight gradient, in the
+    # backward - so under autograd it only pays for batches of at least `freq_domain_min_batch` cubes
+    # (full-size training step, batch 2 per GPU: 102 ms direct vs 140 ms in the frequency domain, measured).
+    freq_domain = True
+    freq_domain_min_batch = 8
+
     def forward(self, x):
         cin = self.in_channels
         have = x.shape[1]
+        if self.freq_domain and x.is_cuda and x.dtype == torch.float32 and self.kernel_size == (7, 7, 7) and \
+                self.stride == (1, 1, 1) and self.padding == (3, 3, 3) and self.dilation == (1, 1, 1) and \
+                self.groups == 1 and have >= cin and \
+                (not torch.is_grad_enabled() or x.shape[0] >= self.freq_domain_min_batch):
+            return _FreqConv3d.apply(x[:, :cin] if have > cin else x, self.weight, self.bias)
         target = have if have > cin else ((cin + 3) // 4 * 4 if cin >= 3 else cin)
         if target == cin:
             return super().forward(x)
@@ -177,18 +256,7 @@ class _FoldedV2V:
         x = _lib.channel_shift_act_(F.conv3d(x, w0, None, 1, 3), s0, 1)
         return self._tail(x)
 
-    @staticmethod
-    def _fft_len(n):
-        """smallest even m >= n whose prime factors are <= 13 (rocFFT radices)"""
-        m = n + (n & 1)
-        while True:
-            r = m
-            for q in (2, 3, 5, 7, 11, 13):
-                while r % q == 0:
-                    r //= q
-            if r == 1:
-                return m
-            m += 2
+    _fft_len = staticmethod(fft_len)
 
     def _front_fft(self, x, w0, s0):
         """the 7x7x7 opening conv in the frequency domain: zero-padded rFFT (rocFFT via torch.fft) ->

@@ -612,3 +612,33 @@ def test_freq_contract_and_fft_opening_conv(dev, shape):
     err_fft = float((y.double() - ref64).abs().max())
     err_direct = float((direct.double() - ref64).abs().max())
     assert err_fft <= max(2.0 * err_direct, 2e-5), (err_fft, err_direct)
+
+
+@pytest.mark.parametrize("shape", [(2, 15, 16, (12, 8, 8), True), (3, 4, 6, (8, 8, 4), False), (1, 16, 16, (8, 12, 8), True)])
+def test_freq_domain_conv_autograd(dev, shape):
+    """_FreqConv3d (the 7x7x7 opening conv, forward and backward in the frequency domain) against float64 autograd
+    of the direct convolution: output, grad input, grad weight, grad bias."""
+    import torch.nn.functional as F
+    from selfpose3d_amd.v2v_net import _FreqConv3d
+    B, C, O, (X, Y, Z), with_bias = shape
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.rand((B, C, X, Y, Z), generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn((O, C, 7, 7, 7), generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = (torch.randn((O,), generator=g)).to(dev).requires_grad_(True) if with_bias else None
+    gy = torch.randn((B, O, X, Y, Z), generator=g).to(dev)
+    y = _FreqConv3d.apply(x, w, b)
+    y.backward(gy)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    b64 = b.detach().double().requires_grad_(True) if with_bias else None
+    y64 = F.conv3d(x64, w64, b64, padding=3)
+    y64.backward(gy.double())
+    tol = lambda ref: 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((y.double() - y64).abs().max()) <= tol(y64)
+    assert float((x.grad.double() - x64.grad).abs().max()) <= tol(x64.grad)
+    assert float((w.grad.double() - w64.grad).abs().max()) <= tol(w64.grad)
+    if with_bias:
+        assert float((b.grad.double() - b64.grad).abs().max()) <= tol(b64.grad)
+    # channels-last activations come back channels-last
+    xcl = x.detach().contiguous(memory_format=torch.channels_last_3d)
+    ycl = _FreqConv3d.apply(xcl, w.detach(), None)
+    assert ycl.is_contiguous(memory_format=torch.channels_last_3d) or C == 1
