@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-baseline-reps", type=int, default=6)
     ap.add_argument("--front-conv", choices=["fft", "direct"], default="fft",
                     help="7x7x7 opening conv of V2V: frequency domain (rocFFT + sp3d_freq_contract) or MIOpen direct")
+    ap.add_argument("--no-winograd", action="store_true",
+                    help="keep the 1/2- and 1/4-resolution 3x3x3 convs on MIOpen instead of Winograd F(2,3) (HIP transforms + rocBLAS)")
     ap.add_argument("--v2v-layout", choices=["ncdhw", "cl3d"], default="cl3d",
                     help="memory format of the V2V stack (fp32 either way)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one HIP graph")
@@ -52,7 +54,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft"):
+def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winograd=True):
     from selfpose3d_amd import synthetic as syn
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
@@ -67,6 +69,7 @@ def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft"):
     if v2v_layout == "cl3d":
         model.use_channels_last(True)
     model.v2v_net.fft_front = front_conv == "fft"
+    model.v2v_net.winograd = bool(winograd)
     return cfg, meta, hms, model
 
 
@@ -193,7 +196,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     torch.backends.cudnn.benchmark = True
-    cfg, meta, hms, model = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv)
+    cfg, meta, hms, model = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv, not args.no_winograd)
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
@@ -250,8 +253,9 @@ def main():
                        "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
                        "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(fp32: 7^3 opening conv " +
                                ("rocFFT+HIP contraction" if args.front_conv == "fft" else "MIOpen direct") +
+                               (", wide low-res 3^3 convs Winograd F(2,3) (HIP transforms + rocBLAS)" if not args.no_winograd else "") +
                                ", other convs MIOpen) -> NMS/top-k(HIP)",
-                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "launch": mode},
+                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
         }
         result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, cold=args.cold)

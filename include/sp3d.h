@@ -207,6 +207,18 @@ int sp3d_freq_contract(const float *X, const float *W, float *Y, int B, int C, i
 int sp3d_freq_contract_ex(const float *P, const float *Q, float *Y, int I, int J, int K, int64_t F, int64_t sPi,
                           int64_t sPk, int64_t sQj, int64_t sQk, int conj_p, int conj_q, void *stream);
 
+/*
+ * Winograd F(2x2x2, 3x3x3) transforms for the low-resolution 3x3x3 convolutions of V2VNet in inference
+ * (lib/models/v2v_net.py:23-45 at 1/4 resolution): channels-last activations only.
+ *   sp3d_wino_input   x (B,X,Y,Z,C) -> V (64, T, C),  T = B*ceil(X/2)*ceil(Y/2)*ceil(Z/2)  (B^T d B per axis)
+ *   [caller: M = bmm(V, U) with U (64, C, O) = G g G^T of the weights]
+ *   sp3d_wino_output  M (64, T, O) -> y (B,X,Y,Z,O) = A^T m A, + shift[o] (+ residual) (+ ReLU): mode as in
+ *                     sp3d_channel_shift_act (0 shift, 1 relu(shift), 2 relu(shift+res), 3 relu(shift)+res)
+ */
+int sp3d_wino_input(const float *x, float *V, int B, int X, int Y, int Z, int C, void *stream);
+int sp3d_wino_output(const float *M, float *y, const float *shift, const float *residual, int mode, int B, int X, int Y,
+                     int Z, int O, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output",
 ]
 
 _lib = None
@@ -74,6 +74,10 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_wino_input.restype = I
+    lib.sp3d_wino_input.argtypes = [P, P, I, I, I, I, I, V]
+    lib.sp3d_wino_output.restype = I
+    lib.sp3d_wino_output.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
     lib.sp3d_freq_contract_ex.restype = I
     lib.sp3d_freq_contract_ex.argtypes = [P, P, P, I, I, I] + [C.c_int64] * 5 + [I, I, V]
     lib.sp3d_freq_contract.restype = I
@@ -372,3 +376,36 @@ def freq_contract_ex(Pf: torch.Tensor, Qf: torch.Tensor, mode: str) -> torch.Ten
     check(lib.sp3d_freq_contract_ex(Pf.data_ptr(), Qf.data_ptr(), Y.data_ptr(), I, J, K, Fn, sPi, sPk, sQj, sQk, cp, cq,
                                     _stream(Pf.device)), "sp3d_freq_contract_ex")
     return Y
+
+
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def wino_weights(w: torch.Tensor) -> torch.Tensor:
+    """(O,C,3,3,3) conv weights -> U (64, C, O) = G g G^T along each axis (Winograd F(2,3))"""
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum("ai,bj,ck,ozijk->abczo", G, G, G, w.double())
+    return u.reshape(64, w.shape[1], w.shape[0]).float().contiguous()
+
+
+def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3x3 stride-1 'same' conv of channels-last x (B,C,X,Y,Z as torch.channels_last_3d) with pre-transformed weights
+    U (64,C,O), fused with the layer epilogue; returns a channels_last_3d tensor (B,O,X,Y,Z)."""
+    lib = load()
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("wino_conv3d_: float32 channels_last_3d activations expected")
+    O = int(U.shape[2])
+    T = B * ((X + 1) // 2) * ((Y + 1) // 2) * ((Z + 1) // 2)
+    V = torch.empty((64, T, Cc), dtype=torch.float32, device=x.device)
+    check(lib.sp3d_wino_input(x.data_ptr(), V.data_ptr(), B, X, Y, Z, Cc, _stream(x.device)), "sp3d_wino_input")
+    M = torch.bmm(V, U)
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
+        residual = residual.contiguous(memory_format=torch.channels_last_3d)
+    check(lib.sp3d_wino_output(M.data_ptr(), y.data_ptr(), shift.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, O,
+                               _stream(x.device)), "sp3d_wino_output")
+    return y

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip"]
+SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip"]
 HEADERS = ["sp3d_device.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
 LIB = os.path.join(HERE, "libsp3d.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -211,13 +211,17 @@ class _FoldedV2V:
         n, t = self.net, {}
         t["front"] = self._fold(n.front_layers[0].block[0], n.front_layers[0].block[1])
         def res(name, blk):
+            from . import _lib
             w1, s1 = self._fold(blk.res_branch[0], blk.res_branch[1])
             w2, s2 = self._fold(blk.res_branch[3], blk.res_branch[4])
+            # Winograd-domain weights for the wide (low-resolution) layers, see _conv3
+            u1 = _lib.wino_weights(w1) if w1.is_cuda and w1.shape[1] >= 64 else None
+            u2 = _lib.wino_weights(w2) if w2.is_cuda and w2.shape[1] >= 64 else None
             if len(blk.skip_con) > 0:
                 ws, ss = self._fold(blk.skip_con[0], blk.skip_con[1])
-                t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws)
+                t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws, u1, u2)
             else:
-                t[name] = (w1, s1, w2, s2, None)
+                t[name] = (w1, s1, w2, s2, None, u1, u2)
         res("front_res", n.front_layers[1])
         ed = n.encoder_decoder
         for name in ("encoder_res1", "encoder_res2", "mid_res", "decoder_res2", "decoder_res1", "skip_res1", "skip_res2"):
@@ -227,13 +231,26 @@ class _FoldedV2V:
             t[name] = self._fold(blk[0], blk[1], transposed=True)
         self.t = t
 
-    def _res(self, x, name):
+    def _conv3(self, x, w, u, shift, mode, residual=None):
+        """3x3x3 conv + fused epilogue.  Wide layers on small grids (the 1/4- and 1/2-resolution blocks: a GEMM with
+        few rows, where MIOpen's implicit-GEMM kernels drop to ~60 TFLOP/s) go through Winograd F(2x2x2,3x3x3):
+        HIP input/output transforms around one batched rocBLAS GEMM, 2.1x faster at (4,128,20,20,5) and 1.2x at
+        (4,64,40,40,10) (tools/exp_wino.py); the rule below keeps the transformed tensor (64*T*C floats) within
+        reach of the Infinity Cache, beyond which the transforms eat the gain."""
         from . import _lib
-        w1, s1, w2, s2, ws = self.t[name]
-        h = _lib.channel_shift_act_(F.conv3d(x, w1, None, 1, 1), s1, 1)
-        u = F.conv3d(h, w2, None, 1, 1)
+        if u is not None and self.net.winograd and x.is_contiguous(memory_format=torch.channels_last_3d) \
+                and not x.is_contiguous():
+            B, C, X, Y, Z = x.shape
+            T = B * ((X + 1) // 2) * ((Y + 1) // 2) * ((Z + 1) // 2)
+            if C >= 128 or 64 * T * C * 4 <= 160e6:
+                return _lib.wino_conv3d_(x, u, shift, mode, residual)
+        return _lib.channel_shift_act_(F.conv3d(x, w, None, 1, 1), shift, mode, residual)
+
+    def _res(self, x, name):
+        w1, s1, w2, s2, ws, u1, u2 = self.t[name]
+        h = self._conv3(x, w1, u1, s1, 1)
         r = x if ws is None else F.conv3d(x, ws, None, 1, 0)
-        return _lib.channel_shift_act_(u, s2, 2, r)
+        return self._conv3(h, w2, u2, s2, 2, r)
 
     @torch.no_grad()
     def run(self, x):
@@ -308,6 +325,7 @@ class V2VNet(nn.Module):
         self.output_layer = nn.Conv3d(32, output_channels, 1, 1, 0)
         self.fused_inference = True      # eval + no_grad + GPU: BatchNorm-folded plan with fused epilogues
         self.fft_front = True            # ... whose 7x7x7 opening conv runs in the frequency domain (rocFFT)
+        self.winograd = True             # ... and whose wide low-resolution 3x3x3 convs run as Winograd F(2,3)
         self._plan = None
         self.reset_parameters()
 

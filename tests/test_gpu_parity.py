@@ -642,3 +642,28 @@ def test_freq_domain_conv_autograd(dev, shape):
     xcl = x.detach().contiguous(memory_format=torch.channels_last_3d)
     ycl = _FreqConv3d.apply(xcl, w.detach(), None)
     assert ycl.is_contiguous(memory_format=torch.channels_last_3d) or C == 1
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 128, (20, 20, 5), 1), (2, 64, 128, (6, 5, 3), 2), (1, 8, 4, (4, 4, 4), 0), (3, 16, 32, (7, 9, 2), 3)])
+def test_winograd_conv3d_with_fused_epilogue(dev, shape):
+    """sp3d_wino_input -> bmm -> sp3d_wino_output == conv3d(3x3x3, pad 1) + shift (+ residual) (+ ReLU), odd grid sizes
+    included; float64 is the referee."""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, O, (X, Y, Z), mode = shape
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn((B, C, X, Y, Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((O, C, 3, 3, 3), generator=g) * 0.05).to(dev)
+    shift = torch.randn((O,), generator=g).to(dev)
+    res = torch.randn((B, O, X, Y, Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    U = _lib.wino_weights(w)
+    y = _lib.wino_conv3d_(x, U, shift, mode, res if mode >= 2 else None)
+    ref = F.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, O, 1, 1, 1)
+    if mode == 2:
+        ref = ref + res.double()
+    if mode >= 1:
+        ref = ref.clamp_min(0)
+    if mode == 3:
+        ref = ref + res.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    assert float((y.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
