@@ -218,6 +218,10 @@ int sp3d_freq_contract_ex(const float *P, const float *Q, float *Y, int I, int J
 int sp3d_wino_input(const float *x, float *V, int B, int X, int Y, int Z, int C, void *stream);
 int sp3d_wino_output(const float *M, float *y, const float *shift, const float *residual, int mode, int B, int X, int Y,
                      int Z, int O, void *stream);
+/* the same convolution in ONE launch for the full-resolution layers (C = 16 | 32 -> O = 32): transforms, the 64 products
+ * (v_mfma_f32_32x32x2_f32) and the epilogue fused, U (64, C, 32) as above, x / y channels-last */
+int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode, int B,
+                    int X, int Y, int Z, int C, int O, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_wino_fused.restype = I
+    lib.sp3d_wino_fused.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, V]
     lib.sp3d_wino_input.restype = I
     lib.sp3d_wino_input.argtypes = [P, P, I, I, I, I, I, V]
     lib.sp3d_wino_output.restype = I
@@ -408,4 +410,22 @@ def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: in
     check(lib.sp3d_wino_output(M.data_ptr(), y.data_ptr(), shift.data_ptr(),
                                residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, O,
                                _stream(x.device)), "sp3d_wino_output")
+    return y
+
+
+def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
+                       residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one-launch Winograd 3x3x3 conv (C = 16 | 32 -> O = 32) of channels_last_3d x with the fused epilogue"""
+    lib = load()
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("wino_fused_conv3d_: float32 channels_last_3d activations expected")
+    O = int(U.shape[2])
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
+        residual = residual.contiguous(memory_format=torch.channels_last_3d)
+    check(lib.sp3d_wino_fused(x.data_ptr(), U.data_ptr(), y.data_ptr(), shift.data_ptr(),
+                              residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
+                              _stream(x.device)), "sp3d_wino_fused")
     return y

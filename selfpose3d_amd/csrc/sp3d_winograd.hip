@@ -161,3 +161,176 @@ extern "C" int sp3d_wino_output(const float *M, float *y, const float *shift, co
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused Winograd F(2x2x2, 3x3x3) for the FULL-resolution 3x3x3 layers (C = 16 or 32 -> O = 32), where the
+// transformed tensor of the three-launch form above would be 524 MB.  One wave = a block of 4x4x2 tiles (8x8x4
+// outputs x 32 channels); nothing but x, U and y touches memory:
+//   per chunk of 8 input channels: stage the 10x10x6 input region in LDS (21.6 KB);
+//   per transform point: each lane builds its A operand on the fly - V[p][tile][c] is a signed sum of 8 region
+//     voxels (B^T has two non-zeros per row) - B = U[p][c][o] streams from L2, and v_mfma_f32_32x32x2_f32
+//     (tiles x outputs, K = 8 channels) accumulates;
+//   the inverse transform is linear: along x it is folded into the MFMA accumulation, along y,z it is applied to
+//     the accumulators on the VALU; nothing transformed is ever stored.
+// ------------------------------------------------------------------------------------------
+namespace sp3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WF_RX = 10, WF_RY = 10, WF_RZ = 6;
+constexpr int WF_VS = 8;                       // floats per staged voxel (one chunk of 8 input channels)
+constexpr int WF_ROW = WF_RX * WF_VS + 1;      // odd row pitch: spreads the tiles' (y,z) rows over the LDS banks
+constexpr int WF_LDS = WF_RY * WF_RZ * WF_ROW; // 4 860 floats = 19.4 KB -> 8 waves per CU
+
+// B^T rows as (first tap +, second tap, sign of second): d0-d2, d1+d2, d2-d1, d1-d3
+__device__ constexpr int wf_ta(int r) { return r == 0 ? 0 : (r == 1 ? 1 : (r == 2 ? 2 : 1)); }
+__device__ constexpr int wf_tb(int r) { return r == 0 ? 2 : (r == 1 ? 2 : (r == 2 ? 1 : 3)); }
+__device__ constexpr float wf_sb(int r) { return r == 1 ? 1.0f : -1.0f; }
+// A^T = [[1,1,1,0],[0,1,-1,-1]]
+__device__ constexpr float wf_at(int a, int r) { return a == 0 ? (r < 3 ? 1.0f : 0.0f) : (r == 0 ? 0.0f : (r == 1 ? 1.0f : -1.0f)); }
+
+template <int C, int MODE>
+__global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict__ x, const float *__restrict__ U,
+                                                       float *__restrict__ y, const float *__restrict__ shift,
+                                                       const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
+                                                       int NBY, int NBZ)
+{
+    constexpr int O = 32;
+    __shared__ float region[WF_LDS];
+    const int lane = threadIdx.x, t = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int bz = bid % NBZ; bid /= NBZ;
+    const int by = bid % NBY; bid /= NBY;
+    const int bx = bid % NBX;
+    const int b = bid / NBX;
+    const int ttx = t & 3, tty = (t >> 2) & 3, ttz = t >> 4;
+    const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 4;                 // first output voxel of the block
+    // region address of (vx,vy,vz,c) = (vz*RY + vy)*ROW + vx*VS + c; this tile's patch origin, + c = 2*kk + h
+    const float *rb = region + ((2 * ttz) * WF_RY + 2 * tty) * WF_ROW + (2 * ttx) * WF_VS + h;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][v] = 0.0f;
+
+#pragma unroll 1
+    for (int cc = 0; cc < C / 8; ++cc) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // stage 600 voxels x 8 channels = 1200 float4, 5 loads in flight per lane
+#pragma unroll 1
+        for (int i0 = 0; i0 < WF_RX * WF_RY * WF_RZ * 2; i0 += 64 * 5) {
+            float4 d[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = i0 + u * 64 + lane;
+                const int v = idx >> 1, half = idx & 1;
+                const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
+                const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
+                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx < WF_RX * WF_RY * WF_RZ * 2 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z)
+                    d[u] = *reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + cc * 8 + half * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = i0 + u * 64 + lane;
+                if (idx < WF_RX * WF_RY * WF_RZ * 2) {
+                    const int v = idx >> 1, half = idx & 1;
+                    const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
+                    float *r = region + (vz * WF_RY + vy) * WF_ROW + vx * WF_VS + half * 4;
+                    r[0] = d[u].x; r[1] = d[u].y; r[2] = d[u].z; r[3] = d[u].w;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float *ub = U + ((int64_t)(cc * 8 + h)) * O + t;             // + p*C*O + 2*kk*O
+        // (y,z) index of the transform point: run-time loop; x index: unrolled.  The inverse transform along x is
+        // folded into the MFMA accumulation (two accumulators, A^T = [1,1,1,0] / [0,1,-1,-1] as +-A operands), the one
+        // along y,z is applied once per (j,k) on the VALU with wave-uniform coefficients.
+#pragma unroll 1
+        for (int jk = 0; jk < 16; ++jk) {
+            const int j = jk >> 2, k = jk & 3;
+            const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
+            const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
+            const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
+            const float *r00 = rb + (za * WF_RY + ya) * WF_ROW, *r10 = rb + (za * WF_RY + yb) * WF_ROW;
+            const float *r01 = rb + (zb * WF_RY + ya) * WF_ROW, *r11 = rb + (zb * WF_RY + yb) * WF_ROW;
+            const float *uj = ub + (int64_t)jk * C * O;
+            float g[4][4];                                                 // [x tap][kk]: y,z transform done
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int o = xi * WF_VS + 2 * kk;
+                    g[xi][kk] = fmaf(sz, fmaf(sy, r11[o], r01[o]), fmaf(sy, r10[o], r00[o]));
+                }
+            f32x16 M0, M1;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { M0[v] = 0.0f; M1[v] = 0.0f; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float av = (i == 1) ? g[1][kk] + g[2][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk];
+                    const float bv = uj[(int64_t)(i * 16) * C * O + 2 * kk * O];
+                    if (i < 3) M0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M0, 0, 0, 0);
+                    if (i > 0) M1 = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 1 ? av : -av, bv, M1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int bc = 0; bc < 4; ++bc) {
+                const int bb = bc >> 1, c2 = bc & 1;
+                const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
+                const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
+                const float coef = cy * cz;
+                if (coef != 0.0f) {
+                    acc[bc] += M0 * coef;
+                    acc[4 + bc] += M1 * coef;
+                }
+            }
+        }
+    }
+
+    const float sh = shift[t];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = 8 * (v >> 2) + (v & 3) + 4 * h;              // tile of this accumulator element
+            const int rx = row & 3, ry = (row >> 2) & 3, rz = row >> 4;
+            const int xo = ox0 + 2 * rx + (a >> 2), yo = oy0 + 2 * ry + ((a >> 1) & 1), zo = oz0 + 2 * rz + (a & 1);
+            if (xo < X && yo < Y && zo < Z) {
+                const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t;
+                float val = acc[a][v] + sh;
+                if (MODE == 2) val += res[idx];
+                if (MODE >= 1) val = fmaxf(val, 0.0f);
+                if (MODE == 3) val += res[idx];
+                y[idx] = val;
+            }
+        }
+    }
+}
+
+} // namespace sp3d
+
+extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
+                               int B, int X, int Y, int Z, int C, int O, void *stream)
+{
+    using namespace sp3d;
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
+    if (!x || !U || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if (O != 32 || (C != 16 && C != 32)) return SP3D_EUNSUPPORTED;
+    const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 3) / 4;
+    const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
+    if (blocks > 0x7fffffff) return SP3D_ERANGE;
+    const dim3 grid((unsigned)blocks), block(64);
+    hipStream_t s = (hipStream_t)stream;
+#define SP3D_WF(C_, M_) hipLaunchKernelGGL((wino_fused_kernel<C_, M_>), grid, block, 0, s, x, U, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
+#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }
+    if (C == 16) { SP3D_WFM(16) } else { SP3D_WFM(32) }
+#undef SP3D_WFM
+#undef SP3D_WF
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}

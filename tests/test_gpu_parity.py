@@ -667,3 +667,28 @@ def test_winograd_conv3d_with_fused_epilogue(dev, shape):
         ref = ref + res.double()
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
     assert float((y.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, (16, 16, 8), 2), (1, 16, (8, 8, 4), 1), (3, 32, (9, 7, 5), 0), (1, 32, (20, 12, 6), 3), (4, 16, (10, 17, 3), 1)])
+def test_winograd_fused_kernel(dev, shape):
+    """sp3d_wino_fused (one launch: on-the-fly transforms + v_mfma_f32_32x32x2_f32 + epilogue) == conv3d + epilogue,
+    block-edge and odd sizes included; float64 referee."""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, (X, Y, Z), mode = shape
+    O = 32
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = torch.randn((B, C, X, Y, Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((O, C, 3, 3, 3), generator=g) * 0.05).to(dev)
+    shift = torch.randn((O,), generator=g).to(dev)
+    res = torch.randn((B, O, X, Y, Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    y = _lib.wino_fused_conv3d_(x, _lib.wino_weights(w), shift, mode, res if mode >= 2 else None)
+    ref = F.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, O, 1, 1, 1)
+    if mode == 2:
+        ref = ref + res.double()
+    if mode >= 1:
+        ref = ref.clamp_min(0)
+    if mode == 3:
+        ref = ref + res.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    assert float((y.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))

@@ -29,4 +29,13 @@ for name, B, C, O, grid in (("quarter_128_128", 4, 128, 128, (20, 20, 5)), ("qua
     wino = lambda: _lib.wino_conv3d_(x, U, s, 1)
     err = float((direct() - wino()).abs().max())
     out[name] = {"miopen_plus_epilogue_us": round(timed(direct), 1), "winograd_us": round(timed(wino), 1), "max_abs_diff": err}
+for name, B, C, O, grid in (("full_32_32", 4, 32, 32, (80, 80, 20)), ("full_16_32", 4, 16, 32, (80, 80, 20)), ("pose_full_32", 8, 32, 32, (64, 64, 64))):
+    x = torch.randn(B, C, *grid, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(O, C, 3, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last_3d)
+    s = torch.randn(O, device=dev)
+    U = _lib.wino_weights(w)
+    direct = lambda: _lib.channel_shift_act_(F.conv3d(x, w, padding=1), s, 1)
+    fused = lambda: _lib.wino_fused_conv3d_(x, U, s, 1)
+    err = float((direct() - fused()).abs().max())
+    out[name] = {"miopen_plus_epilogue_us": round(timed(direct), 1), "winograd_fused_us": round(timed(fused), 1), "max_abs_diff": err}
 print(json.dumps(out, indent=1))
