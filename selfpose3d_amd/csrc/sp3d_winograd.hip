@@ -249,15 +249,20 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
         // (y,z) index of the transform point: run-time loop; x index: unrolled.  The inverse transform along x is
         // folded into the MFMA accumulation (two accumulators, A^T = [1,1,1,0] / [0,1,-1,-1] as +-A operands), the one
         // along y,z is applied once per (j,k) on the VALU with wave-uniform coefficients.
-#pragma unroll 1
-        for (int jk = 0; jk < 16; ++jk) {
+        // one (j,k) step; bcur = its 16 B operands (fetched one step ahead: they come from L2, ~700 cycles away),
+        // bnxt receives those of step jk_next
+        auto step = [&](int jk, int jk_next, const float (&bcur)[16], float (&bnxt)[16]) {
             const int j = jk >> 2, k = jk & 3;
             const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
             const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
             const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
             const float *r00 = rb + (za * WF_RY + ya) * WF_ROW, *r10 = rb + (za * WF_RY + yb) * WF_ROW;
             const float *r01 = rb + (zb * WF_RY + ya) * WF_ROW, *r11 = rb + (zb * WF_RY + yb) * WF_ROW;
-            const float *uj = ub + (int64_t)jk * C * O;
+            const float *un = ub + (int64_t)jk_next * C * O;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bnxt[i * 4 + kk] = un[(int64_t)(i * 16) * C * O + 2 * kk * O];
             float g[4][4];                                                 // [x tap][kk]: y,z transform done
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi)
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const float av = (i == 1) ? g[1][kk] + g[2][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk];
-                    const float bv = uj[(int64_t)(i * 16) * C * O + 2 * kk * O];
+                    const float bv = bcur[i * 4 + kk];
                     if (i < 3) M0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M0, 0, 0, 0);
                     if (i > 0) M1 = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 1 ? av : -av, bv, M1, 0, 0, 0);
                 }
@@ -285,10 +290,23 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                 const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
                 const float coef = cy * cz;
                 if (coef != 0.0f) {
-                    acc[bc] += M0 * coef;
-                    acc[4 + bc] += M1 * coef;
+                    f32x16 cv;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) cv[v] = coef;
+                    acc[bc] = __builtin_elementwise_fma(M0, cv, acc[bc]);
+                    acc[4 + bc] = __builtin_elementwise_fma(M1, cv, acc[4 + bc]);
                 }
             }
+        };
+        float b0[16], b1[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b0[i * 4 + kk] = ub[(int64_t)(i * 16) * C * O + 2 * kk * O];
+#pragma unroll 1
+        for (int jk = 0; jk < 16; jk += 2) {
+            step(jk, jk + 1, b0, b1);
+            step(jk + 1, (jk + 2) & 15, b1, b0);
         }
     }
 
