@@ -176,6 +176,12 @@ extern "C" int sp3d_wino_output(const float *M, float *y, const float *shift, co
 namespace sp3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef SP3D_WF_TIMELINE
+__device__ unsigned long long *g_wf_tl = nullptr;
+#define WF_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (tl && lane == 0) tl[slot] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WF_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int WF_RX = 10, WF_RY = 10, WF_RZ = 6;
 constexpr int WF_VS = 8;                       // floats per staged voxel (one chunk of 8 input channels)
@@ -213,6 +219,10 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][v] = 0.0f;
+#ifdef SP3D_WF_TIMELINE
+    unsigned long long *tl = g_wf_tl ? g_wf_tl + (size_t)blockIdx.x * 80 : nullptr;
+#endif
+    WF_STAMP(0);
 
 #pragma unroll 1
     for (int cc = 0; cc < C / 8; ++cc) {
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                     const int o = xi * WF_VS + 2 * kk;
                     g[xi][kk] = fmaf(sz, fmaf(sy, r11[o], r01[o]), fmaf(sy, r10[o], r00[o]));
                 }
+            if (cc == 0) WF_STAMP(8 + 4 * jk);                             // operands ready
             f32x16 M0, M1;
 #pragma unroll
             for (int v = 0; v < 16; ++v) { M0[v] = 0.0f; M1[v] = 0.0f; }
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                     if (i < 3) M0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M0, 0, 0, 0);
                     if (i > 0) M1 = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 1 ? av : -av, bv, M1, 0, 0, 0);
                 }
+            if (cc == 0) WF_STAMP(9 + 4 * jk);                             // MFMAs issued
 #pragma unroll
             for (int bc = 0; bc < 4; ++bc) {
                 const int bb = bc >> 1, c2 = bc & 1;
@@ -297,6 +309,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                     acc[4 + bc] = __builtin_elementwise_fma(M1, cv, acc[4 + bc]);
                 }
             }
+            if (cc == 0) WF_STAMP(10 + 4 * jk);                            // accumulated
         };
         float b0[16], b1[16];
 #pragma unroll
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
         }
     }
 
+    WF_STAMP(5);                                                           // all chunks done
     const float sh = shift[t];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
@@ -351,4 +365,15 @@ extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const f
 #undef SP3D_WF
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_debug_wino_fused_timeline(void *dev_buffer)
+{
+#ifdef SP3D_WF_TIMELINE
+    unsigned long long *p = (unsigned long long *)dev_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sp3d::g_wf_tl), &p, sizeof(p));
+#else
+    (void)dev_buffer;
+    return SP3D_EUNSUPPORTED;
+#endif
 }
