@@ -282,6 +282,15 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                     g[xi][kk] = fmaf(sz, fmaf(sy, r11[o], r01[o]), fmaf(sy, r10[o], r00[o]));
                 }
             if (cc == 0) WF_STAMP(8 + 4 * jk);                             // operands ready
+            // wave-uniform y,z coefficients of A^T for the four (b,c) output positions
+            float cyz[4];
+#pragma unroll
+            for (int bc = 0; bc < 4; ++bc) {
+                const int bb = bc >> 1, c2 = bc & 1;
+                const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
+                const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
+                cyz[bc] = cy * cz;
+            }
             f32x16 M0, M1;
 #pragma unroll
             for (int v = 0; v < 16; ++v) { M0[v] = 0.0f; M1[v] = 0.0f; }
@@ -297,10 +306,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
             if (cc == 0) WF_STAMP(9 + 4 * jk);                             // MFMAs issued
 #pragma unroll
             for (int bc = 0; bc < 4; ++bc) {
-                const int bb = bc >> 1, c2 = bc & 1;
-                const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
-                const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
-                const float coef = cy * cz;
+                const float coef = cyz[bc];
                 if (coef != 0.0f) {
                     f32x16 cv;
 #pragma unroll
