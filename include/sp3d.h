@@ -223,6 +223,14 @@ int sp3d_wino_output(const float *M, float *y, const float *shift, const float *
 int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode, int B,
                     int X, int Y, int Z, int C, int O, void *stream);
 
+/*
+ * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
+ * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):
+ * out (batch,2X,2Y,2Z,O channels-last) = relu(G + shift[o]) + skip.
+ */
+int sp3d_upsample2x_scatter(const float *G, float *out, const float *shift, const float *skip, int64_t batch, int X, int Y,
+                            int Z, int O, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

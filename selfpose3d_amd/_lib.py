@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter",
 ]
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_upsample2x_scatter.restype = I
+    lib.sp3d_upsample2x_scatter.argtypes = [P, P, P, P, C.c_int64, I, I, I, I, V]
     lib.sp3d_wino_fused.restype = I
     lib.sp3d_wino_fused.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, V]
     lib.sp3d_wino_input.restype = I
@@ -429,3 +431,21 @@ def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mo
                               residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
                               _stream(x.device)), "sp3d_wino_fused")
     return y
+
+
+def upsample2x_(x: torch.Tensor, w_gemm: torch.Tensor, shift: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose3d(k=2,s=2) + shift + ReLU + skip on channels_last_3d activations: one rocBLAS GEMM on the
+    (voxels, Cin) view with w_gemm (Cin, 8*O) [columns (i,j,k,o)] + sp3d_upsample2x_scatter."""
+    lib = load()
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("upsample2x_: float32 channels_last_3d activations expected")
+    O = int(w_gemm.shape[1]) // 8
+    G = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, Cc), w_gemm)
+    out = torch.empty((B, 2 * X, 2 * Y, 2 * Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    if skip.shape != out.shape or skip.stride() != out.stride():
+        skip = skip.contiguous(memory_format=torch.channels_last_3d)
+    check(lib.sp3d_upsample2x_scatter(G.data_ptr(), out.data_ptr(), shift.data_ptr(), skip.data_ptr(), B, X, Y, Z, O,
+                                      _stream(x.device)), "sp3d_upsample2x_scatter")
+    return out

@@ -71,3 +71,57 @@ extern "C" int sp3d_channel_shift_act(float *y, const float *shift, const float 
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
+
+// ------------------------------------------------------------------------------------------
+// ConvTranspose3d(kernel 2, stride 2) (lib/models/v2v_net.py:57-69) has no overlapping taps: every output voxel
+// (2x+i, 2y+j, 2z+k) depends on input voxel (x,y,z) only, so the layer is ONE GEMM  G[n, (i,j,k,o)] = X[n,:] . W[:, (i,j,k,o)]
+// (rocBLAS through torch.matmul on the channels-last view) followed by this scatter, which also applies the layer's
+// epilogue: out = relu(G + shift[o]) + skip   (mode 3 of sp3d_channel_shift_act), channels-last in and out.
+// ------------------------------------------------------------------------------------------
+namespace sp3d {
+
+__global__ __launch_bounds__(256) void upsample2x_scatter_kernel(const float *__restrict__ G, float *__restrict__ out,
+                                                                const float *__restrict__ shift,
+                                                                const float *__restrict__ skip, int64_t n_in, int X, int Y,
+                                                                int Z, int O)
+{
+    const int64_t total = n_in * 8 * (O / 4);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int q = O / 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int o4 = (int)(e % q);
+        int64_t r = e / q;
+        const int ijk = (int)(r & 7);
+        const int64_t n = r >> 3;                              // input voxel (b,x,y,z) flattened
+        const int z = (int)(n % Z); int64_t m = n / Z;
+        const int y = (int)(m % Y); m /= Y;
+        const int x = (int)(m % X);
+        const int64_t b = m / X;
+        const int xo = 2 * x + (ijk >> 2), yo = 2 * y + ((ijk >> 1) & 1), zo = 2 * z + (ijk & 1);
+        const int64_t oi = ((((b * (2 * X) + xo) * (2 * Y) + yo) * (2 * Z) + zo) * O) + 4 * o4;
+        const float4 g = *reinterpret_cast<const float4 *>(G + (n * 8 + ijk) * O + 4 * o4);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + 4 * o4);
+        const float4 k = *reinterpret_cast<const float4 *>(skip + oi);
+        float4 v;
+        v.x = fmaxf(g.x + s.x, 0.0f) + k.x; v.y = fmaxf(g.y + s.y, 0.0f) + k.y;
+        v.z = fmaxf(g.z + s.z, 0.0f) + k.z; v.w = fmaxf(g.w + s.w, 0.0f) + k.w;
+        *reinterpret_cast<float4 *>(out + oi) = v;
+    }
+}
+
+} // namespace sp3d
+
+extern "C" int sp3d_upsample2x_scatter(const float *G, float *out, const float *shift, const float *skip, int64_t batch, int X,
+                                       int Y, int Z, int O, void *stream)
+{
+    if (batch <= 0 || X <= 0 || Y <= 0 || Z <= 0 || O <= 0) return SP3D_EINVAL;
+    if (!G || !out || !shift || !skip) return SP3D_ENULL;
+    if (O & 3) return SP3D_EUNSUPPORTED;
+    const int64_t n_in = batch * X * Y * Z;
+    const int64_t total = n_in * 8 * (O / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(sp3d::upsample2x_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, out, shift, skip, n_in,
+                       X, Y, Z, O);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}

@@ -229,7 +229,10 @@ class _FoldedV2V:
             res(name, getattr(ed, name))
         for name in ("decoder_upsample2", "decoder_upsample1"):
             blk = getattr(ed, name).block
-            t[name] = self._fold(blk[0], blk[1], transposed=True)
+            wT, sT = self._fold(blk[0], blk[1], transposed=True)
+            # (Cin, Cout, 2,2,2) -> GEMM form (Cin, 8*Cout), columns ordered (i,j,k,o): see _up2x
+            wg = wT.permute(0, 2, 3, 4, 1).reshape(wT.shape[0], 8 * wT.shape[1]).contiguous()
+            t[name] = (wT, sT, wg)
         self.t = t
 
     def _conv3(self, x, w, u, shift, mode, residual=None):
@@ -255,7 +258,7 @@ class _FoldedV2V:
     def _res(self, x, name):
         w1, s1, w2, s2, ws, u1, u2 = self.t[name]
         h = self._conv3(x, w1, u1, s1, 1)
-        r = x if ws is None else F.conv3d(x, ws, None, 1, 0)
+        r = x if ws is None else self._conv1(x, ws)
         return self._conv3(h, w2, u2, s2, 2, r)
 
     @torch.no_grad()
@@ -314,13 +317,35 @@ class _FoldedV2V:
         skip2 = self._res(x, "skip_res2")
         x = self._res(F.max_pool3d(x, 2, 2), "encoder_res2")
         x = self._res(self._res(x, "mid_res"), "decoder_res2")
-        wT, sT = self.t["decoder_upsample2"]
-        x = _lib.channel_shift_act_(F.conv_transpose3d(x, wT, None, 2), sT, 3, skip2)
+        x = self._up2x(x, "decoder_upsample2", skip2)
         x = self._res(x, "decoder_res1")
-        wT, sT = self.t["decoder_upsample1"]
-        x = _lib.channel_shift_act_(F.conv_transpose3d(x, wT, None, 2), sT, 3, skip1)
+        x = self._up2x(x, "decoder_upsample1", skip1)
         o = self.net.output_layer
-        return F.conv3d(x, o.weight, o.bias)
+        return self._conv1(x, o.weight, o.bias)
+
+    @staticmethod
+    def _is_cl(x):
+        return x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous()
+
+    def _up2x(self, x, name, skip):
+        """ConvTranspose3d(2, stride 2) + BN + ReLU + skip: no overlapping taps, so on channels-last activations it is
+        one GEMM + a scatter with the epilogue (sp3d_upsample2x_scatter) instead of MIOpen's backward-data kernel"""
+        from . import _lib
+        wT, sT, wg = self.t[name]
+        if self.net.winograd and self._is_cl(x) and wg.is_cuda and wT.shape[1] % 4 == 0:
+            return _lib.upsample2x_(x, wg, sT, skip)
+        return _lib.channel_shift_act_(F.conv_transpose3d(x, wT, None, 2), sT, 3, skip)
+
+    def _conv1(self, x, w, bias=None):
+        """1x1x1 conv: on channels-last activations a plain (voxels, Cin) x (Cin, Cout) GEMM on the same memory"""
+        if self.net.winograd and self._is_cl(x) and x.is_cuda:
+            B, C, X, Y, Z = x.shape
+            O = w.shape[0]
+            y = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, C), w.reshape(O, C).t())
+            if bias is not None:
+                y = y + bias
+            return y.view(B, X, Y, Z, O).permute(0, 4, 1, 2, 3)
+        return F.conv3d(x, w, bias, 1, 0)
 
 
 class V2VNet(nn.Module):

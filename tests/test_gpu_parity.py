@@ -692,3 +692,21 @@ def test_winograd_fused_kernel(dev, shape):
         ref = ref + res.double()
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
     assert float((y.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 64, (5, 5, 2)), (2, 64, 32, (4, 6, 3)), (1, 8, 4, (2, 2, 2))])
+def test_upsample2x_gemm_scatter(dev, shape):
+    """ConvTranspose3d(2, stride 2) as one GEMM + sp3d_upsample2x_scatter == conv_transpose3d + shift + ReLU + skip"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, O, (X, Y, Z) = shape
+    g = torch.Generator(device="cpu").manual_seed(13)
+    x = torch.randn((B, C, X, Y, Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((C, O, 2, 2, 2), generator=g) * 0.1).to(dev)
+    shift = torch.randn((O,), generator=g).to(dev)
+    skip = torch.randn((B, O, 2 * X, 2 * Y, 2 * Z), generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    wg = w.permute(0, 2, 3, 4, 1).reshape(C, 8 * O).contiguous()
+    y = _lib.upsample2x_(x, wg, shift, skip)
+    ref = (F.conv_transpose3d(x.double(), w.double(), stride=2) + shift.double().view(1, O, 1, 1, 1)).clamp_min(0) + skip.double()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
