@@ -923,7 +923,10 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
                        float *cubes, float *grids, const Geom &g_in, int variant, bool out_cl, int io, hipStream_t s)
 {
     Geom g = g_in;
-    g.xcd_order = ((variant >> 21) & 1) ? 0 : 1;             // centre-out chunk order unless tuning bit 21 asks for the plain sweep
+    // chunk order: centre of the volume first (cheap edge tiles form the tail) when a sample is spread over >= 4 XCDs
+    // (-2.5 % at B = 1); with 2 XCDs per sample it buys no time and costs L2 locality (HBM-side reads 75 -> 92 MB on
+    // the bench workload), so the plain sweep stays there.  Tuning bit 21 forces the sweep.
+    g.xcd_order = (!((variant >> 21) & 1) && g.B <= 2) ? 1 : 0;
     if ((variant >> 17) & 15) {
         g.xcd_chunk = 1 << (((variant >> 17) & 15) - 1);   // tuning bits 17-20: log2(K)+1
     } else {
