@@ -383,199 +383,3 @@ extern "C" int sp3d_debug_wino_fused_timeline(void *dev_buffer)
     return SP3D_EUNSUPPORTED;
 #endif
 }
-
-extern "C" int sp3d_debug_wino_fused_timeline(void *dev_buffer)
-{
-#ifdef SP3D_WF_TIMELINE
-    unsigned long long *p = (unsigned long long *)dev_buffer;
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sp3d::g_wf_tl), &p, sizeof(p));
-#else
-    (void)dev_buffer;
-    return SP3D_EUNSUPPORTED;
-#endif
-}
-
-// ------------------------------------------------------------------------------------------
-// Second form of the fused kernel: 16 tiles (4x4x1) x 32 outputs per task on v_mfma_f32_16x16x4_f32 (two 16-column
-// blocks), grid-stride over the tasks.  Same arithmetic and fold as wino_fused_kernel; the smaller accumulator set
-// (64 + 16 registers instead of 128 + 32) lets three waves share a SIMD, the finer tasks balance better.
-// ------------------------------------------------------------------------------------------
-namespace sp3d {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int W16_RX = 10, W16_RY = 10, W16_RZ = 4;
-constexpr int W16_ROW = W16_RX * WF_VS + 1;
-constexpr int W16_LDS = W16_RY * W16_RZ * W16_ROW;          // 3 240 floats = 13 KB
-
-template <int C, int MODE>
-__global__ __launch_bounds__(64) void wino_fused16_kernel(const float *__restrict__ x, const float *__restrict__ U,
-                                                         float *__restrict__ y, const float *__restrict__ shift,
-                                                         const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
-                                                         int NBY, int NBZ, int ntasks)
-{
-    constexpr int O = 32;
-    __shared__ float region[W16_LDS];
-    const int lane = threadIdx.x, t = lane & 15, ks = lane >> 4;
-    const int ttx = t & 3, tty = t >> 2;
-    const float *rb = region + (2 * tty) * W16_ROW + (2 * ttx) * WF_VS + ks;      // + c = 4*s + ks
-
-#pragma unroll 1
-    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
-        int bid = task;
-        const int bz = bid % NBZ; bid /= NBZ;
-        const int by = bid % NBY; bid /= NBY;
-        const int bx = bid % NBX;
-        const int b = bid / NBX;
-        const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 2;
-        f32x4 acc[8][2];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) acc[a][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-
-#pragma unroll 1
-        for (int cc = 0; cc < C / 8; ++cc) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-            for (int i0 = 0; i0 < W16_RX * W16_RY * W16_RZ * 2; i0 += 64 * 5) {
-                float4 d[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int idx = i0 + u * 64 + lane;
-                    const int v = idx >> 1, half = idx & 1;
-                    const int vx = v % W16_RX, vy = (v / W16_RX) % W16_RY, vz = v / (W16_RX * W16_RY);
-                    const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
-                    d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (idx < W16_RX * W16_RY * W16_RZ * 2 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z)
-                        d[u] = *reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + cc * 8 + half * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int idx = i0 + u * 64 + lane;
-                    if (idx < W16_RX * W16_RY * W16_RZ * 2) {
-                        const int v = idx >> 1, half = idx & 1;
-                        const int vx = v % W16_RX, vy = (v / W16_RX) % W16_RY, vz = v / (W16_RX * W16_RY);
-                        float *r = region + (vz * W16_RY + vy) * W16_ROW + vx * WF_VS + half * 4;
-                        r[0] = d[u].x; r[1] = d[u].y; r[2] = d[u].z; r[3] = d[u].w;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float *ub = U + ((int64_t)(cc * 8 + ks)) * O + t;          // + p*C*O + 4*s*O + 16*col
-            auto step = [&](int jk, int jk_next, const float (&bcur)[16], float (&bnxt)[16]) {
-                const int j = jk >> 2, k = jk & 3;
-                const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
-                const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
-                const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
-                const float *r00 = rb + (za * W16_RY + ya) * W16_ROW, *r10 = rb + (za * W16_RY + yb) * W16_ROW;
-                const float *r01 = rb + (zb * W16_RY + ya) * W16_ROW, *r11 = rb + (zb * W16_RY + yb) * W16_ROW;
-                const float *un = ub + (int64_t)jk_next * C * O;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) bnxt[(i * 2 + s) * 2 + q] = un[(int64_t)(i * 16) * C * O + 4 * s * O + 16 * q];
-                float g[4][2];
-#pragma unroll
-                for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int o = xi * WF_VS + 4 * s;
-                        g[xi][s] = fmaf(sz, fmaf(sy, r11[o], r01[o]), fmaf(sy, r10[o], r00[o]));
-                    }
-                f32x4 M0[2], M1[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { M0[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; M1[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float av = (i == 1) ? g[1][s] + g[2][s] : g[wf_ta(i)][s] - g[wf_tb(i)][s];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const float bv = bcur[(i * 2 + s) * 2 + q];
-                            if (i < 3) M0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, M0[q], 0, 0, 0);
-                            if (i > 0) M1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(i == 1 ? av : -av, bv, M1[q], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                for (int bc = 0; bc < 4; ++bc) {
-                    const int bb = bc >> 1, c2 = bc & 1;
-                    const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
-                    const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
-                    const float coef = cy * cz;
-                    if (coef != 0.0f) {
-                        const f32x4 cv = (f32x4){coef, coef, coef, coef};
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            acc[bc][q] = __builtin_elementwise_fma(M0[q], cv, acc[bc][q]);
-                            acc[4 + bc][q] = __builtin_elementwise_fma(M1[q], cv, acc[4 + bc][q]);
-                        }
-                    }
-                }
-            };
-            float b0[16], b1[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) b0[(i * 2 + s) * 2 + q] = ub[(int64_t)(i * 16) * C * O + 4 * s * O + 16 * q];
-#pragma unroll 1
-            for (int jk = 0; jk < 16; jk += 2) {
-                step(jk, jk + 1, b0, b1);
-                step(jk + 1, (jk + 2) & 15, b1, b0);
-            }
-        }
-
-        // D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int o = 16 * q + t;
-                const float sh = shift[o];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * ks + r;
-                    const int xo = ox0 + 2 * (row & 3) + (a >> 2), yo = oy0 + 2 * (row >> 2) + ((a >> 1) & 1), zo = oz0 + (a & 1);
-                    if (xo < X && yo < Y && zo < Z) {
-                        const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o;
-                        float val = acc[a][q][r] + sh;
-                        if (MODE == 2) val += res[idx];
-                        if (MODE >= 1) val = fmaxf(val, 0.0f);
-                        if (MODE == 3) val += res[idx];
-                        y[idx] = val;
-                    }
-                }
-            }
-    }
-}
-
-} // namespace sp3d
-
-extern "C" int sp3d_wino_fused16(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
-                                 int B, int X, int Y, int Z, int C, int O, int max_waves, void *stream)
-{
-    using namespace sp3d;
-    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
-    if (!x || !U || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
-    if (O != 32 || (C != 16 && C != 32)) return SP3D_EUNSUPPORTED;
-    const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 1) / 2;
-    const int64_t tasks = (int64_t)B * NBX * NBY * NBZ;
-    if (tasks > 0x7fffffff) return SP3D_ERANGE;
-    const int waves = (int)(tasks < (max_waves > 0 ? max_waves : 2048) ? tasks : (max_waves > 0 ? max_waves : 2048));
-    const dim3 grid((unsigned)waves), block(64);
-    hipStream_t s = (hipStream_t)stream;
-#define SP3D_WF(C_, M_) hipLaunchKernelGGL((wino_fused16_kernel<C_, M_>), grid, block, 0, s, x, U, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)tasks)
-#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }
-    if (C == 16) { SP3D_WFM(16) } else { SP3D_WFM(32) }
-#undef SP3D_WFM
-#undef SP3D_WF
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SP3D_OK : (int)e;
-}
