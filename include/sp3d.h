@@ -194,6 +194,16 @@ int sp3d_gaussian_target_3d(const float *roots, int B, int R, const float *gx, c
                             int Y, int Z, float sigma, float *target, void *stream);
 int sp3d_render_root_heatmaps(const float *roots, int B, int R, const float *cam, int V, int h, int w, float stride,
                               float *out, void *stream);
+/*
+ * Differentiable joint rendering of the self-supervised pose loss (lib/models/multi_person_posenet_ssv.py:409-465):
+ * kps (N, P, J, 2) projected joints in heat-map pixels (N = views x samples), count (N) people per entry (NULL: P),
+ * out (N, J, h, w) = clip(sum over people of sigma-Gaussians, 0, 1); _bwd returns d loss / d kps given d loss / d out.
+ * P <= 16.
+ */
+int sp3d_render_joints_fwd(const float *kps, const int *count, int N, int P, int J, int h, int w, float sigma, float *out,
+                           void *stream);
+int sp3d_render_joints_bwd(const float *kps, const int *count, const float *grad_out, int N, int P, int J, int h, int w,
+                           float sigma, float *grad_kps, void *stream);
 
 /*
  * Channel contraction of a frequency-domain convolution (the 7x7x7 opening conv of V2VNet, lib/models/v2v_net.py:

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -76,6 +76,10 @@ def load():
     lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_upsample2x_scatter.restype = I
     lib.sp3d_upsample2x_scatter.argtypes = [P, P, P, P, C.c_int64, I, I, I, I, V]
+    lib.sp3d_render_joints_fwd.restype = I
+    lib.sp3d_render_joints_fwd.argtypes = [P, P, I, I, I, I, I, F, P, V]
+    lib.sp3d_render_joints_bwd.restype = I
+    lib.sp3d_render_joints_bwd.argtypes = [P, P, P, I, I, I, I, I, F, P, V]
     lib.sp3d_wino_fused.restype = I
     lib.sp3d_wino_fused.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, V]
     lib.sp3d_wino_input.restype = I
@@ -449,3 +453,36 @@ def upsample2x_(x: torch.Tensor, w_gemm: torch.Tensor, shift: torch.Tensor, skip
     check(lib.sp3d_upsample2x_scatter(G.data_ptr(), out.data_ptr(), shift.data_ptr(), skip.data_ptr(), B, X, Y, Z, O,
                                       _stream(x.device)), "sp3d_upsample2x_scatter")
     return out
+
+
+class _RenderJoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kps, count, h, w, sigma):
+        lib = load()
+        _require_cuda(kps, "kps")
+        N, Pn, J = (int(v) for v in kps.shape[:3])
+        k = kps.contiguous().float()
+        cnt = None if count is None else count.to(device=kps.device, dtype=torch.int32).contiguous()
+        out = torch.empty((N, J, h, w), dtype=torch.float32, device=kps.device)
+        check(lib.sp3d_render_joints_fwd(k.data_ptr(), cnt.data_ptr() if cnt is not None else None, N, Pn, J, h, w,
+                                         float(sigma), out.data_ptr(), _stream(kps.device)), "sp3d_render_joints_fwd")
+        ctx.save_for_backward(k, cnt if cnt is not None else torch.empty(0, device=kps.device))
+        ctx.geom = (h, w, float(sigma), cnt is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = load()
+        k, cnt = ctx.saved_tensors
+        h, w, sigma, has_cnt = ctx.geom
+        N, Pn, J = (int(v) for v in k.shape[:3])
+        g = gout.contiguous().float()
+        gk = torch.empty_like(k)
+        check(lib.sp3d_render_joints_bwd(k.data_ptr(), cnt.data_ptr() if has_cnt else None, g.data_ptr(), N, Pn, J, h, w,
+                                         sigma, gk.data_ptr(), _stream(k.device)), "sp3d_render_joints_bwd")
+        return gk, None, None, None, None
+
+
+def render_joint_heatmaps(kps: torch.Tensor, count: Optional[torch.Tensor], h: int, w: int, sigma: float = 3.0):
+    """kps (N,P,J,2) heat-map pixels, count (N,) people per entry or None -> (N,J,h,w), differentiable in kps"""
+    return _RenderJoints.apply(kps, count, int(h), int(w), float(sigma))

@@ -103,3 +103,124 @@ extern "C" int sp3d_render_root_heatmaps(const float *roots, int B, int R, const
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
+
+// ------------------------------------------------------------------------------------------
+// Differentiable joint heat-map rendering of the self-supervised pose loss (reference:
+// lib/models/multi_person_posenet_ssv.py:409-465): for every (view, sample) the projected joints of the P predicted
+// people are rendered as sigma-3 Gaussians, summed over people and clipped,
+//     out[n, j, y, x] = clip( sum_p exp(-((x - kx)/s)^2/2 - ((y - ky)/s)^2/2), 0, 1 ),     kps (N, P, J, 2) heat-map px
+// (the reference builds a (P, J, h, w) temporary per (view, sample) in Python loops).  Backward: torch.clip passes the
+// gradient where the sum is <= 1; d/dkx of a Gaussian is g * (x - kx) / s^2 - one workgroup per (n, j) recomputes the
+// sum per pixel and reduces the 2P partial derivatives over the image.
+// ------------------------------------------------------------------------------------------
+namespace sp3d {
+
+constexpr int RJ_MAXP = 16;
+
+__global__ __launch_bounds__(256) void render_joints_fwd_kernel(const float *__restrict__ kps, const int *__restrict__ count,
+                                                               int P, int J, int h, int w, float sigma,
+                                                               float *__restrict__ out)
+{
+    __shared__ float sk[2 * RJ_MAXP];
+    const int n = blockIdx.z, j = blockIdx.y;
+    const int np = count ? min(count[n], P) : P;
+    if (threadIdx.x < np) {
+        const float *k = kps + (((size_t)n * P + threadIdx.x) * J + j) * 2;
+        sk[2 * threadIdx.x] = k[0]; sk[2 * threadIdx.x + 1] = k[1];
+    }
+    __syncthreads();
+    float *o = out + ((size_t)n * J + j) * h * w;
+    for (int pidx = blockIdx.x * 256 + threadIdx.x; pidx < h * w; pidx += gridDim.x * 256) {
+        const float yy = (float)(pidx / w), xx = (float)(pidx % w);
+        float s = 0.0f;
+        for (int p = 0; p < np; ++p) {
+            const float ex = (xx - sk[2 * p]) / sigma, ey = (yy - sk[2 * p + 1]) / sigma;
+            s += expf(-(ex * ex) / 2.0f - (ey * ey) / 2.0f);
+        }
+        o[pidx] = fminf(fmaxf(s, 0.0f), 1.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void render_joints_bwd_kernel(const float *__restrict__ kps, const int *__restrict__ count,
+                                                               const float *__restrict__ gout, int P, int J, int h, int w,
+                                                               float sigma, float *__restrict__ gkps)
+{
+    __shared__ float sk[2 * RJ_MAXP];
+    __shared__ float red[4][2 * RJ_MAXP];
+    const int n = blockIdx.y, j = blockIdx.x;
+    const int np = count ? min(count[n], P) : P;
+    if (threadIdx.x < np) {
+        const float *k = kps + (((size_t)n * P + threadIdx.x) * J + j) * 2;
+        sk[2 * threadIdx.x] = k[0]; sk[2 * threadIdx.x + 1] = k[1];
+    }
+    __syncthreads();
+    float acc[2 * RJ_MAXP];
+#pragma unroll
+    for (int q = 0; q < 2 * RJ_MAXP; ++q) acc[q] = 0.0f;
+    const float *g = gout + ((size_t)n * J + j) * h * w;
+    const float inv2 = 1.0f / (sigma * sigma);
+    for (int pidx = threadIdx.x; pidx < h * w; pidx += 256) {
+        const float yy = (float)(pidx / w), xx = (float)(pidx % w);
+        float gp[RJ_MAXP];
+        float s = 0.0f;
+#pragma unroll
+        for (int p = 0; p < RJ_MAXP; ++p) {
+            gp[p] = 0.0f;
+            if (p < np) {
+                const float ex = (xx - sk[2 * p]) / sigma, ey = (yy - sk[2 * p + 1]) / sigma;
+                gp[p] = expf(-(ex * ex) / 2.0f - (ey * ey) / 2.0f);
+                s += gp[p];
+            }
+        }
+        const float go = (s <= 1.0f) ? g[pidx] : 0.0f;            // clip(., 0, 1) backward; the sum is never negative
+#pragma unroll
+        for (int p = 0; p < RJ_MAXP; ++p)
+            if (p < np) {
+                const float c = go * gp[p] * inv2;
+                acc[2 * p] += c * (xx - sk[2 * p]);
+                acc[2 * p + 1] += c * (yy - sk[2 * p + 1]);
+            }
+    }
+    // wave reduction, then across the four waves
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 2 * RJ_MAXP; ++q) {
+        float v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * P) {
+        const int p = threadIdx.x >> 1, c = threadIdx.x & 1;
+        float v = 0.0f;
+        if (p < np) v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        gkps[(((size_t)n * P + p) * J + j) * 2 + c] = v;
+    }
+}
+
+} // namespace sp3d
+
+extern "C" int sp3d_render_joints_fwd(const float *kps, const int *count, int N, int P, int J, int h, int w, float sigma,
+                                      float *out, void *stream)
+{
+    if (N <= 0 || P <= 0 || P > sp3d::RJ_MAXP || J <= 0 || h <= 0 || w <= 0 || !(sigma > 0.0f)) return SP3D_EINVAL;
+    if (!kps || !out) return SP3D_ENULL;
+    if (N > 65535 || J > 65535) return SP3D_ERANGE;
+    const int blocks = (h * w + 255) / 256 < 32 ? (h * w + 255) / 256 : 32;
+    hipLaunchKernelGGL(sp3d::render_joints_fwd_kernel, dim3(blocks, J, N), dim3(256), 0, (hipStream_t)stream, kps, count, P, J, h,
+                       w, sigma, out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_render_joints_bwd(const float *kps, const int *count, const float *grad_out, int N, int P, int J, int h,
+                                      int w, float sigma, float *grad_kps, void *stream)
+{
+    if (N <= 0 || P <= 0 || P > sp3d::RJ_MAXP || J <= 0 || h <= 0 || w <= 0 || !(sigma > 0.0f)) return SP3D_EINVAL;
+    if (!kps || !grad_out || !grad_kps) return SP3D_ENULL;
+    if (N > 65535) return SP3D_ERANGE;
+    hipLaunchKernelGGL(sp3d::render_joints_bwd_kernel, dim3(J, N), dim3(256), 0, (hipStream_t)stream, kps, count, grad_out, P, J,
+                       h, w, sigma, grad_kps);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}

@@ -159,3 +159,37 @@ def test_synthetic_root_branch_kernels_match_reference_golden_and_torch_path():
     for a, b in zip(h_c, h_g):
         assert float((a - b.cpu()).abs().max()) <= 2e-5
     assert float(t_g.max()) > 0.5 and float(h_g[0].max()) > 0.0
+
+
+@pytest.mark.gpu
+def test_differentiable_joint_rendering_matches_reference_formula():
+    """sp3d_render_joints_fwd/bwd against the reference's expression (multi_person_posenet_ssv.py:416-423:
+    exp(-((xx - x)/3)^2/2 - ((yy - y)/3)^2/2), summed over people, clipped) evaluated by torch in float64, values and
+    gradients w.r.t. the projected joints; ragged people counts per (view, sample)."""
+    from selfpose3d_amd import _lib
+    dev = torch.device("cuda:0")
+    N, P, J, h, w = 6, 4, 15, 32, 48
+    g = torch.Generator(device="cpu").manual_seed(17)
+    kps = torch.stack([torch.rand((N, P, J), generator=g) * (w + 8) - 4, torch.rand((N, P, J), generator=g) * (h + 8) - 4], -1)
+    kps[0, 1] = kps[0, 0] + 0.5                                    # overlapping people: the clip becomes active
+    count = torch.tensor([4, 2, 0, 1, 3, 4], dtype=torch.int32)
+    wgt = torch.randn((N, J, h, w), generator=g)
+    k_gpu = kps.to(dev).requires_grad_(True)
+    out = _lib.render_joint_heatmaps(k_gpu, count, h, w, 3.0)
+    (out * wgt.to(dev)).sum().backward()
+    k64 = kps.double().requires_grad_(True)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(w, dtype=torch.float64), indexing="ij")
+    ref = []
+    for n in range(N):
+        kk = k64[n, :int(count[n])]                                # (p, J, 2)
+        x, y = kk[..., 0, None, None], kk[..., 1, None, None]
+        hm = torch.exp(-(((xx - x) / 3.0) ** 2) / 2 - (((yy - y) / 3.0) ** 2) / 2)      # (p, J, h, w)
+        ref.append(torch.clip(hm.sum(0), min=0.0, max=1.0) if count[n] > 0 else torch.zeros(J, h, w, dtype=torch.float64))
+    ref = torch.stack(ref, 0)
+    (ref * wgt.double()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-6
+    gk = k_gpu.grad.cpu().double()
+    scale = max(1.0, float(k64.grad.abs().max()))
+    assert float((gk - k64.grad).abs().max()) <= 2e-5 * scale
+    assert float(gk[2].abs().max()) == 0.0 and float(gk[1, 2:].abs().max()) == 0.0     # people beyond the count get no gradient
+    assert float(out.detach().max()) == 1.0                                             # the clip was exercised
