@@ -79,6 +79,14 @@ def make_cfg(image_size, heatmap_size, space_size, space_center, cube, fine_grid
     )
 
 
+def camera_pack_affine(meta_v, b, img):
+    from selfpose3d_amd.camera_pack import get_affine_transform_batch
+    c = meta_v["center"].numpy()[b:b + 1]
+    sc = meta_v["scale"].numpy()[b:b + 1]
+    rot = np.asarray(meta_v["rotation"], np.float64)[b:b + 1]
+    return get_affine_transform_batch(c, sc, rot, img)[0]
+
+
 def main():
     _install_shims()
     from models.project_layer import ProjectLayer
@@ -124,6 +132,28 @@ def main():
         proj.append(rcams.project_pose(torch.from_numpy(pts), cam).numpy())
     np.savez(os.path.join(HERE, "project_pose.npz"), pts=pts, px=np.stack(proj))
     print("project_pose:", np.stack(proj).shape)
+
+    # ------------------------------------------------------------------ batched reprojection of predicted poses (f3)
+    # cameras.project_pose_batch (cameras.py:58-118): no r^2 clamp, crop affine applied, ragged people per sample
+    rngb = np.random.default_rng(23)
+    Bp, Vp, people = 2, 5, [3, 2]
+    metab = syn.random_meta(Bp, Vp, (960, 512), seed=5, augment=True, ssv_style=True)
+    transb = torch.from_numpy(np.stack([camera_pack_affine(metab[0], b, (960, 512)) for b in range(Bp)]).astype(np.float32))
+    poses = [torch.from_numpy(rngb.uniform([-1500, -2000, 0], [1500, 1000, 1800], size=(n, 15, 3)).astype(np.float32))
+             for n in people]
+    outb = []
+    for v in range(Vp):
+        cam = dict(metab[v]["camera"])
+        cam["f"] = torch.stack([cam["fx"], cam["fy"]], -1).view(Bp, 2, 1)
+        cam["c"] = torch.stack([cam["cx"], cam["cy"]], -1).view(Bp, 2, 1)
+        res = rcams.project_pose_batch([q.clone() for q in poses], cam, transb)
+        outb.append([r.numpy() for r in res])
+    rec = {"trans": transb.numpy(), "people": np.array(people)}
+    for bi in range(Bp):
+        rec[f"pose{bi}"] = poses[bi].numpy()
+        rec[f"px{bi}"] = np.stack([outb[v][bi] for v in range(Vp)])
+    np.savez_compressed(os.path.join(HERE, "project_pose_batch.npz"), **rec)
+    print("project_pose_batch:", rec["px0"].shape, rec["px1"].shape)
 
     # ------------------------------------------------------------------ unprojection (a2,a3,a6-a12)
     def run_project(name, B, V, J, img, hm, grid_size, grid_center, cube, hm_kind="random", seed=0,

@@ -193,3 +193,42 @@ def test_differentiable_joint_rendering_matches_reference_formula():
     assert float((gk - k64.grad).abs().max()) <= 2e-5 * scale
     assert float(gk[2].abs().max()) == 0.0 and float(gk[1, 2:].abs().max()) == 0.0     # people beyond the count get no gradient
     assert float(out.detach().max()) == 1.0                                             # the clip was exercised
+
+
+@pytest.mark.gpu
+def test_reprojection_heatmaps_gradient_reaches_the_3d_joints():
+    """3D poses -> project_joints (torch, differentiable) -> sp3d_render_joints (HIP fwd/bwd): the MSE against target
+    heat-maps has the same value and the same gradient w.r.t. the poses as the all-torch float64 evaluation."""
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.camera_pack import pack_cameras
+    from selfpose3d_amd.reprojection import project_joints, reprojection_heatmaps
+    dev = torch.device("cuda:0")
+    B, V, P, J, h, w = 2, 5, 3, 15, 128, 240
+    meta = syn.make_meta(B, V, (960, 512), ssv_style=True)
+    cam = torch.from_numpy(pack_cameras(meta, B, (960, 512)))
+    g = torch.Generator(device="cpu").manual_seed(29)
+    joints = torch.stack([torch.rand((B, P, J), generator=g) * 3000 - 1500, torch.rand((B, P, J), generator=g) * 3000 - 2000,
+                          torch.rand((B, P, J), generator=g) * 1600 + 100], -1)
+    count = torch.tensor([3, 2], dtype=torch.int32)
+    target = torch.rand((V, B, J, h, w), generator=g)
+    jg = joints.to(dev).requires_grad_(True)
+    hm = reprojection_heatmaps(jg, count, cam.to(dev), h, w)
+    loss = torch.nn.functional.mse_loss(hm, target.to(dev))
+    loss.backward()
+    j64 = joints.double().requires_grad_(True)
+    kps = project_joints(j64, cam.double(), 4.0)                                   # (V,B,P,J,2)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(w, dtype=torch.float64), indexing="ij")
+    ref = torch.zeros(V, B, J, h, w, dtype=torch.float64)
+    rows = []
+    for v in range(V):
+        for b in range(B):
+            kk = kps[v, b, :int(count[b])]
+            x, y = kk[..., 0, None, None], kk[..., 1, None, None]
+            rows.append(torch.clip(torch.exp(-(((xx - x) / 3.0) ** 2) / 2 - (((yy - y) / 3.0) ** 2) / 2).sum(0), 0.0, 1.0))
+    ref = torch.stack(rows, 0).view(V, B, J, h, w)
+    loss64 = torch.nn.functional.mse_loss(ref, target.double())
+    loss64.backward()
+    assert abs(float(loss.detach()) - float(loss64.detach())) <= 1e-6
+    gs = max(1e-12, float(j64.grad.abs().max()))
+    assert float((jg.grad.cpu().double() - j64.grad).abs().max()) <= 2e-3 * gs
+    assert float(jg.grad[1, 2].abs().max()) == 0.0                                  # person beyond the count

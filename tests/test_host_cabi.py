@@ -227,3 +227,25 @@ def test_fft_lengths_for_the_opening_conv():
             while r % q == 0:
                 r //= q
         assert r == 1
+
+
+def test_project_joints_matches_reference_project_pose_batch():
+    """vectorised reprojection of predicted poses == cameras.project_pose_batch of the reference (golden generated by
+    tests/golden/make_goldens.py: random rigs, augmented crops, ragged people per sample)"""
+    from selfpose3d_amd.camera_pack import pack_cameras
+    from selfpose3d_amd.reprojection import project_joints
+    from tests import golden_io as gio
+    g = gio.load("project_pose_batch")
+    people = [int(n) for n in g["people"]]
+    B, V, P = len(people), 5, max(people)
+    meta = syn.random_meta(B, V, (960, 512), seed=5, augment=True, ssv_style=True)
+    cam = torch.from_numpy(pack_cameras(meta, B, (960, 512)))
+    joints = torch.zeros(B, P, 15, 3)
+    for b in range(B):
+        joints[b, :people[b]] = torch.from_numpy(g[f"pose{b}"])
+    px = project_joints(joints, cam, stride=1.0, trans=torch.from_numpy(g["trans"]))      # (V,B,P,J,2)
+    for b in range(B):
+        ref = g[f"px{b}"]                                                                  # (V, people, J, 2)
+        got = px[:, b, :people[b]].numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= 2e-5 * scale, (b, np.abs(got - ref).max())
