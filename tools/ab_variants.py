@@ -45,6 +45,9 @@ def main():
         "coarse_b1_v5": dict(B=1, V=5, cube=syn.INITIAL_CUBE_SIZE, gs=syn.SPACE_SIZE, fine=False),
         "stress_b1_v10": dict(B=1, V=10, cube=(160, 160, 40), gs=syn.SPACE_SIZE, fine=False),
         "fine_b10_v5": dict(B=10, V=5, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),
+        # BASELINE configs[4]: 3-4 view rigs (Campus / Shelf style), fine per-person cubes; the bf16 rows are its storage mode
+        "fine_b10_v3": dict(B=10, V=3, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),
+        "fine_b10_v4": dict(B=10, V=4, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),
     }
     report = {}
     for name, wl in workloads.items():
