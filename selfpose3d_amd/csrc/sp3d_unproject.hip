@@ -37,6 +37,19 @@ __device__ unsigned long long *g_timeline = nullptr;
 #define SP3D_STAMP_ALWAYS(slot) do { } while (0)
 #endif
 
+// measurement only (tools/diag_ablate.py builds one library per -DSP3D_ABLATE=<mask>, never shipped): compile-time
+// switches that REMOVE one part of the pipelined kernels (results are then wrong on purpose) to see how the parts
+// compose in time.  1: no result stores  2: no tap loads (FMAs run on zeros)  4: no projection (synthetic tap
+// records)  8: staggered start (s_sleep by wave slot)  16: no FMAs
+#ifndef SP3D_ABLATE
+#define SP3D_ABLATE 0
+#endif
+#define SP3D_DIAG_ON(bit) ((SP3D_ABLATE) & (bit))
+#define SP3D_DIAG_FLAGS() do { } while (0)
+#if SP3D_ABLATE
+#define SP3D_DIAG
+#endif
+
 constexpr int TILE = 256; // voxels per workgroup (= threads per workgroup)
 
 // ------------------------------------------------------------------------------------------
@@ -371,53 +384,36 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
     return r;
 }
 
-template <int JP, int NW, bool OUTCL, typename TI, typename TO, int U = 4>
-__device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restrict__ cam, const float *__restrict__ centers,
-                                          const uint8_t *__restrict__ valid, float *__restrict__ cubes,
-                                          float *__restrict__ grids, const Geom &g, int b, int tile, float *smem,
-                                          unsigned wid)
+// The view loop shared by the pipelined kernels: P1 (lane = voxel) and G (lane = (voxel-of-4, channel quad)) for the 64
+// voxels of this wave; `x,y,z` is this lane's voxel centre, `inb` whether the lane has a voxel at all.  On return
+// acc[i][k] holds sum over views of the bilinear samples of voxel slot 16*i + lane/4, channel 4*(lane%4) + k, and
+// mymask the bound bits of the lane's own voxel (+ bit 31: NaN sample position).
+template <int JP, typename TI, int U = 4>
+__device__ __forceinline__ void pipe_views(const Views &hm, const float *__restrict__ cam, const Geom &g, int bs, float x,
+                                           float y, float z, bool inb, float *ws, int lane, float (&acc)[4][4],
+                                           uint32_t &mymask, unsigned long long *tl)
 {
     constexpr int NQ = JP / 4;
-    // U = voxel slots gathered per batch of loads (4, 2 and 1 measured equal in the one-tile-per-wave kernel)
-    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
-    (void)wid;
-    const int bs = g.sample_of ? g.sample_of[b] : b;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = tile * (64 * NW) + wave * 64;                          // first voxel of this wave
-    if (n0 >= g.N) return;
-    const int nvox = min(64, g.N - n0);
-    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
-    float *ws = smem + wave * WLDS;
     int *wsi = reinterpret_cast<int *>(ws);
-
-    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
-        for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) Store4<TO>::store1(cb + (OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)), 0.0f);
-        if (grids && lane < nvox) {
-            float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
-            gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
-        }
-        if (g.pass_mask && lane < nvox) g.pass_mask[(size_t)b * g.N + n0 + lane] = 0;
-        return;
+    (void)tl;
+    SP3D_DIAG_FLAGS();
+#ifdef SP3D_DIAG
+    if (SP3D_DIAG_ON(8)) {      // stagger: waves of one SIMD start up to ~1.5k cycles apart
+        const unsigned hw = __builtin_amdgcn_s_getreg(63492);   // HW_ID: wave_id[3:0]
+        for (unsigned k = 0; k < (hw & 3u); ++k) __builtin_amdgcn_s_sleep(8);
     }
-
-    // this lane's voxel (P1 mapping)
-    const bool inb = lane < nvox;
-    const int n = n0 + (inb ? lane : 0);
-    int vx, rem, vy, vz;
-    udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
-    udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
-    const float x = linspace_step(g.Lx, g.stepx, g.X, vx) + centers[3 * b + 0];
-    const float y = linspace_step(g.Ly, g.stepy, g.Y, vy) + centers[3 * b + 1];
-    const float z = linspace_step(g.Lz, g.stepz, g.Z, vz) + centers[3 * b + 2];
-    if (grids && inb) {
-        float *gp = grids + ((size_t)b * g.N + n) * 3;
-        gp[0] = x; gp[1] = y; gp[2] = z;
-    }
-    uint32_t mymask = 0;                        // bound bits of MY voxel (+ bit 31: NaN position)
-
+#endif
     auto P1 = [&](int c) -> bool {
         const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
+#ifdef SP3D_DIAG
+        if (SP3D_DIAG_ON(4)) {      // no projection: a fixed record per lane (distinct pixels, in range)
+            if (inb) mymask |= (1u << c);
+            const int base = (c & 1) * 320 + lane;
+            wsi[base] = (int)((unsigned)(lane * 37 + c * 4001 + 1000 + (int)(x * 0.01f)) % (unsigned)(g.w * (g.h - 2))) * (JP * (int)sizeof(TI));
+            ws[base + 64] = 0.25f; ws[base + 128] = 0.25f; ws[base + 192] = 0.25f; ws[base + 256] = 0.25f;
+            return true;
+        }
+#endif
         float y0, y1, px, py, ix, iy;
         bool isnan;
         proj_a(cm, x, y, z, y0, y1);
@@ -445,17 +441,6 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
     const bool qact = q < NQ;
     const uint32_t qoff = qact ? 4u * (uint32_t)sizeof(TI) * (uint32_t)q : 0u;      // this lane's channel quad, bytes
     const size_t rowf = (size_t)g.w * JP;
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-
-#ifdef SP3D_TIMELINE
-    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)wid * NW + wave) * 32 : nullptr;
-#endif
-    SP3D_STAMP_ALWAYS(0);
-#ifdef SP3D_TIMELINE
-    if (tl && lane == 0) tl[26] = wall_clock64();       // chip-wide 100 MHz clock (cycle counters are per XCD)
-#endif
     bool have = P1(0);
     SP3D_STAMP(1);
 #pragma unroll 1
@@ -476,6 +461,12 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
 #pragma unroll
         for (int gi = 0; gi < 4 / U; ++gi) {
             float4 t00[U], t10[U], t01[U], t11[U];
+#ifdef SP3D_DIAG
+            if (SP3D_DIAG_ON(2)) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) t00[k] = t10[k] = t01[k] = t11[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else
+#endif
             if (cur) {
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
@@ -493,7 +484,7 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
                 __builtin_amdgcn_sched_barrier(0);
                 SP3D_STAMP(4 + 4 * (c < 7 ? c : 6));     // next view projected
             }
-            if (cur) {
+            if (cur && !SP3D_DIAG_ON(16)) {
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     const int i = gi * U + k;
@@ -508,7 +499,68 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
             }
         }
     }
+}
 
+template <int JP, int NW, bool OUTCL, typename TI, typename TO, int U = 4>
+__device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restrict__ cam, const float *__restrict__ centers,
+                                          const uint8_t *__restrict__ valid, float *__restrict__ cubes,
+                                          float *__restrict__ grids, const Geom &g, int b, int tile, float *smem,
+                                          unsigned wid)
+{
+    constexpr int NQ = JP / 4;
+    // U = voxel slots gathered per batch of loads (4, 2 and 1 measured equal in the one-tile-per-wave kernel)
+    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;   // per-wave LDS floats (sOut aliases the records)
+    (void)wid;
+    SP3D_DIAG_FLAGS();
+    const int bs = g.sample_of ? g.sample_of[b] : b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = tile * (64 * NW) + wave * 64;                          // first voxel of this wave
+    if (n0 >= g.N) return;
+    const int nvox = min(64, g.N - n0);
+    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
+    float *ws = smem + wave * WLDS;
+
+    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        for (int j = 0; j < g.J; ++j)
+            if (lane < nvox) Store4<TO>::store1(cb + (OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)), 0.0f);
+        if (grids && lane < nvox) {
+            float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
+            gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+        }
+        if (g.pass_mask && lane < nvox) g.pass_mask[(size_t)b * g.N + n0 + lane] = 0;
+        return;
+    }
+
+    // this lane's voxel (P1 mapping)
+    const bool inb = lane < nvox;
+    const int n = n0 + (inb ? lane : 0);
+    int vx, rem, vy, vz;
+    udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
+    udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
+    const float x = linspace_step(g.Lx, g.stepx, g.X, vx) + centers[3 * b + 0];
+    const float y = linspace_step(g.Ly, g.stepy, g.Y, vy) + centers[3 * b + 1];
+    const float z = linspace_step(g.Lz, g.stepz, g.Z, vz) + centers[3 * b + 2];
+    if (grids && inb) {
+        float *gp = grids + ((size_t)b * g.N + n) * 3;
+        gp[0] = x; gp[1] = y; gp[2] = z;
+    }
+    uint32_t mymask = 0;                        // bound bits of MY voxel (+ bit 31: NaN position)
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
+    const int g16 = lane >> 2, q = lane & 3;
+    const bool qact = q < NQ;
+
+#ifdef SP3D_TIMELINE
+    unsigned long long *tl = g_timeline ? g_timeline + ((size_t)wid * NW + wave) * 32 : nullptr;
+#else
+    unsigned long long *tl = nullptr;
+#endif
+    SP3D_STAMP_ALWAYS(0);
+#ifdef SP3D_TIMELINE
+    if (tl && lane == 0) tl[26] = wall_clock64();       // chip-wide 100 MHz clock (cycle counters are per XCD)
+#endif
+    pipe_views<JP, TI, U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl);
 
     // view fusion (project_layer.py:96-99) on the gather mapping, result tile -> LDS
     __builtin_amdgcn_wave_barrier();
@@ -551,7 +603,7 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
                 float4 o;
                 o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
                 o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                Store4<TO>::store_nt(cb + (size_t)(n0 + nn) * g.J + 4 * q, o);
+                if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)(n0 + nn) * g.J + 4 * q, o);
             }
         } else if (qact) {
 #pragma unroll
@@ -572,7 +624,7 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
         for (int j = lane >> 4; j < g.J; j += 4) {
             const int u = lane & 15;
             const float4 o = *reinterpret_cast<const float4 *>(&ws[j * WOSTR + 4 * u]);
-            Store4<TO>::store_nt(cb + (size_t)j * g.N + n0 + 4 * u, o);
+            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)j * g.N + n0 + 4 * u, o);
         }
     } else {
         for (int j = 0; j < g.J; ++j)
@@ -600,6 +652,146 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     }
     (void)total_tiles;
     pipe_tile<JP, NW, OUTCL, TI, TO>(hm, cam, centers, valid, cubes, grids, g, b, tile, smem, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// "brick" kernel: the same per-wave pipeline, but a wave owns a 4x4x4 block of voxels instead of 64
+// consecutive ones, and a workgroup is a stack of `zw` such bricks along z.
+//
+// Why: the gather is bound by L1 misses, not bytes (profiles/r01_pmc_unproject_coarse_b4.json: 9 L2
+// requests per 16-quad wave-load, TA busy 76 % of the kernel).  64 consecutive voxels are 3.2 z-columns:
+// their projections in one view form 3 well separated vertical runs, and no two voxels of the wave
+// share a 128-B line (2.5 distinct lines per voxel-view on the root grid, 2.3 on the 64^3 person
+// cubes).  A compact brick always has neighbours along every camera's line of sight; those project
+// onto nearly the same pixels: 1.7 lines per voxel-view on the root grid (80 mm voxels, ~4 px apart),
+// 0.6-0.8 on the 64^3 cubes and the 160x160x40 grid (tools/sim_l1.py).
+//
+// Lane -> voxel: lx = lane/16, ly = (lane/4)%4, lz = lane%4 (z fastest, as in memory).  Gather slot i
+// of lane group g16 is voxel 16*i + g16, i.e. (lx, ly, lz) = (i, g16/4, g16%4).
+// Planar results: every wave leaves its (J x 64) tile in LDS, then the workgroup stores whole z-runs:
+// a 16-byte piece = 4 z of one (channel, column), `zw` pieces in a row are contiguous, and so are the
+// 4 y-neighbouring columns (when Y pitch == Z): 4*zw*16-byte runs.  Channels-last results leave from
+// the gather mapping directly (64 B per voxel).
+// ------------------------------------------------------------------------------------------
+constexpr int BR = 4;
+
+template <int JP, bool OUTCL, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
+                                                                const float *__restrict__ centers,
+                                                                const uint8_t *__restrict__ valid,
+                                                                float *__restrict__ cubes, float *__restrict__ grids,
+                                                                Geom g, int wgs_per_sample, int nby, int nzc, int zw)
+{
+    constexpr int NQ = JP / 4;
+    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
+    extern __shared__ __attribute__((aligned(16))) float bsmem[];
+    int b, wg;
+    if (!xcd_map(blockIdx.x, g.B, wgs_per_sample, g.xcd_chunk, b, wg, g.xcd_order)) return;
+    SP3D_DIAG_FLAGS();
+    const int zc = wg % nzc, t = wg / nzc, by = t % nby, bx = t / nby;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = bx * BR, y0 = by * BR, zbase = zc * zw * BR, z0 = zbase + wave * BR;
+    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
+    float *ws = bsmem + wave * WLDS;
+
+    // P1 mapping: this lane's voxel
+    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
+    const int vx = x0 + lx, vy = y0 + ly, vz = z0 + lz;
+    const bool inb = vx < g.X && vy < g.Y && vz < g.Z;
+    const int n = (min(vx, g.X - 1) * g.Y + min(vy, g.Y - 1)) * g.Z + min(vz, g.Z - 1);
+    // gather mapping: slot i of this lane is voxel (x0 + i, y0 + g16/4, z0 + g16%4)
+    const int g16 = lane >> 2, q = lane & 3;
+    const bool qact = q < NQ;
+    const int gy = y0 + (g16 >> 2), gz = z0 + (g16 & 3);
+    const bool ginb = gy < g.Y && gz < g.Z;
+    const int gn0 = (x0 * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);        // + i * YZ
+
+    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        if (inb) {
+            for (int j = 0; j < g.J; ++j)
+                Store4<TO>::store1(cb + (OUTCL ? ((size_t)n * g.J + j) : ((size_t)j * g.N + n)), 0.0f);
+            if (grids) {
+                float *gp = grids + ((size_t)b * g.N + n) * 3;
+                gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+            }
+            if (g.pass_mask) g.pass_mask[(size_t)b * g.N + n] = 0;
+        }
+        return;
+    }
+
+    if (z0 < g.Z) {      // (a stack's last waves may lie above the volume: they only join the barrier)
+        const float x = linspace_step(g.Lx, g.stepx, g.X, min(vx, g.X - 1)) + centers[3 * b + 0];
+        const float y = linspace_step(g.Ly, g.stepy, g.Y, min(vy, g.Y - 1)) + centers[3 * b + 1];
+        const float z = linspace_step(g.Lz, g.stepz, g.Z, min(vz, g.Z - 1)) + centers[3 * b + 2];
+        if (grids && inb) {
+            float *gp = grids + ((size_t)b * g.N + n) * 3;
+            gp[0] = x; gp[1] = y; gp[2] = z;
+        }
+        uint32_t mymask = 0;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
+        pipe_views<JP, TI, 4>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, nullptr);
+
+        // view fusion (project_layer.py:96-99) on the gather mapping
+        __builtin_amdgcn_wave_barrier();
+        const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+        const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float den = __shfl(den_l, 16 * i + g16);
+            const float rden = __shfl(rden_l, 16 * i + g16);      // rden = 0 makes fuse_rcp return exactly 0
+            const bool bad = rden == 0.0f;
+            const bool vin = ginb && (x0 + i < g.X);
+            const int gn = gn0 + i * g.YZ;
+            if (g.pass_mask) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float pre = fuse_pre(acc[i][k], den, rden);
+                    if (!bad && pre >= 0.0f && pre <= 1.0f) bits |= 1u << (4 * q + k);
+                }
+                if (!qact) bits = 0;
+                bits |= (uint32_t)__shfl_xor((int)bits, 1);
+                bits |= (uint32_t)__shfl_xor((int)bits, 2);
+                if (q == 0 && vin) g.pass_mask[(size_t)b * g.N + gn] = (uint16_t)bits;
+            }
+            if (OUTCL) {
+                if (qact && 4 * q < g.J && vin) {
+                    float4 o;
+                    o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
+                    o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
+                    if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)gn * g.J + 4 * q, o);
+                }
+            } else if (qact) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
+            }
+        }
+    }
+    if (OUTCL) return;
+    __syncthreads();
+    // workgroup store of the (J, 4, 4, 4*zw) block: thread -> (channel phase jj, column, brick of the stack)
+    const float rzw = 1.0f / (float)zw;
+    const int per = 16 * zw;                                       // (column, brick) pairs = threads per channel phase
+    const int jj = (int)(((float)(tid >> 4) + 0.5f) * rzw);        // tid / per            (0..3)
+    const int cw = tid - jj * per;
+    const int col = (int)(((float)cw + 0.5f) * rzw), wz = cw - col * zw;
+    const int sx = x0 + (col >> 2), sy = y0 + (col & 3), sz = zbase + wz * BR;
+    if (sx >= g.X || sy >= g.Y || sz >= g.Z) return;
+    const float *tile = bsmem + wz * WLDS + col * 4;
+    TO *dst = cb + ((size_t)sx * g.Y + sy) * g.Z + sz;
+    if ((g.Z & 3) == 0) {
+        for (int j = jj; j < g.J; j += 4) {
+            const float4 o = *reinterpret_cast<const float4 *>(tile + j * WOSTR);
+            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(dst + (size_t)j * g.N, o);
+        }
+    } else {
+        const int nz = min(BR, g.Z - sz);
+        for (int j = jj; j < g.J; j += 4)
+            for (int k = 0; k < nz; ++k) Store4<TO>::store1(dst + (size_t)j * g.N + k, tile[j * WOSTR + k]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -863,6 +1055,43 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
     const size_t lds = (size_t)(JP * OSTR + 2 * g.V * TILE + TILE) * sizeof(float);
     const bool xcd = !(variant & 4);
     dim3 grid(xcd ? xcd_grid_blocks(g.B, tiles, g.xcd_chunk) : total), block(TILE);
+    if (variant & 32) {      // brick kernel: 4x4x4 voxels per wave, a z-stack of bricks per workgroup
+        const int nbx = (g.X + BR - 1) / BR, nby = (g.Y + BR - 1) / BR, nwz = (g.Z + BR - 1) / BR;
+        int nzc = (nwz + 7) / 8, zw = (nwz + nzc - 1) / nzc;
+        if (variant & 64) { zw = 1; nzc = nwz; }                  // tuning: every brick its own workgroup
+        const int wgs = nbx * nby * nzc;
+        Geom gb = g;
+        {   // 2-4 chunks of consecutive workgroups (x-slabs of the volume) per serving XCD
+            const int xps = (g.B <= 8 && (8 % g.B) == 0) ? 8 / g.B : 1;
+            int k = 1;
+            while (k * 2 * xps * 2 <= wgs) k *= 2;
+            if ((variant >> 17) & 15) k = 1 << (((variant >> 17) & 15) - 1);
+            gb.xcd_chunk = k;
+        }
+        constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
+        const size_t blds = (size_t)zw * WLDS * sizeof(float);
+        dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
+#define SP3D_BRICK(CL_, TI_, TO_) \
+    hipLaunchKernelGGL((unproject_brick_kernel<JP, CL_, TI_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
+        if (io != 0) {
+            if constexpr (JP == 16) {
+                switch ((io & 3) * 2 + (out_cl ? 1 : 0)) {
+                case 2: SP3D_BRICK(false, bf16_t, float); break;
+                case 3: SP3D_BRICK(true, bf16_t, float); break;
+                case 4: SP3D_BRICK(false, float, bf16_t); break;
+                case 5: SP3D_BRICK(true, float, bf16_t); break;
+                case 6: SP3D_BRICK(false, bf16_t, bf16_t); break;
+                default: SP3D_BRICK(true, bf16_t, bf16_t); break;
+                }
+                return SP3D_OK;
+            } else {
+                return SP3D_EUNSUPPORTED;
+            }
+        }
+        if (out_cl) SP3D_BRICK(true, float, float); else SP3D_BRICK(false, float, float);
+#undef SP3D_BRICK
+        return SP3D_OK;
+    }
     if (variant & 8) {
         const int nw = (variant & 16) ? 1 : 4;
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
@@ -940,7 +1169,8 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     }
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
-    if ((variant & 8) && (g.w < 2 || g.h < 2)) variant &= ~8;    // the clamped 2x2 block needs a 2x2 image
+    if (g.w < 2 || g.h < 2) variant &= ~(8 | 32);                // the clamped 2x2 block needs a 2x2 image
+    if (variant & 32) variant |= 8;
     if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
     if (io) variant |= 16;
     int rc;
@@ -1153,6 +1383,13 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
     default: hipLaunchKernelGGL((unproject_bwd2_kernel<16, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
     }
     return launch_status();
+}
+
+// measurement only: which -DSP3D_ABLATE mask this library carries (tools/diag_ablate.py)
+extern "C" int sp3d_debug_set_diag(int flags)
+{
+    (void)flags;
+    return SP3D_ABLATE;      // the ablation mask this library was compiled with (0 = the shipped kernels)
 }
 
 // measurement only: set / clear the per-wave timeline buffer of the pipelined kernel

@@ -102,7 +102,10 @@ def validate_3d(config, model, loader, epoch=0, output_dir=None, with_ssv=False,
         if max_iters is not None and i >= max_iters:
             break
         inputs = _to_device(inputs, device)
-        pred, _, grid_centers, _, _, _ = model(views=inputs, meta=meta)
+        if with_ssv:                                                            # function.py:370-376
+            pred, _, grid_centers = model(views1=inputs, meta1=meta, input_heatmaps1=input_heatmap, inference=True)
+        else:
+            pred, _, grid_centers, _, _, _ = model(views=inputs, meta=meta)
         preds.append(pred.detach().cpu())
         gc = grid_centers.detach().cpu()
         roots, nper = meta[0]["roots_3d"].float(), meta[0]["num_person"]

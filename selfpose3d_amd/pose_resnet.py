@@ -62,9 +62,9 @@ _SPEC = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bo
 
 
 class PoseResNet(nn.Module):
-    def __init__(self, cfg):
+    def __init__(self, cfg, num_layers=None):
         super().__init__()
-        block, depths = _SPEC[int(cfg.POSE_RESNET.NUM_LAYERS)]
+        block, depths = _SPEC[int(cfg.POSE_RESNET.NUM_LAYERS if num_layers is None else num_layers)]
         self._cin = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = _bn2(64)
@@ -125,11 +125,21 @@ class PoseResNet(nn.Module):
         return list(y.view(V, B, *y.shape[1:]).unbind(0))
 
 
-def get_pose_net(cfg, is_train: bool = True, **_):
-    """factory with the reference's name/signature (pose_resnet.py:274-284); loads
-    cfg.NETWORK.PRETRAINED when the file exists (ImageNet/COCO initialisation)."""
+class PoseResAttnNet(nn.Module):
+    """attention head of the SSL model: a PoseResNet followed by a sigmoid (pose_resnet.py:287-300; state_dict
+    prefix ``backbone.``)"""
+
+    def __init__(self, cfg, num_layers):
+        super().__init__()
+        self.backbone = PoseResNet(cfg, num_layers)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(self.backbone(x))
+
+
+def _load_pretrained(net, cfg, is_train):
     import os
-    net = PoseResNet(cfg)
     path = str(cfg.NETWORK.get("PRETRAINED", "") or "")
     if is_train and path and os.path.isfile(path):
         sd = torch.load(path, map_location="cpu")
@@ -137,3 +147,16 @@ def get_pose_net(cfg, is_train: bool = True, **_):
         sd = {k: v for k, v in sd.items() if k in own and v.shape == own[k].shape}
         net.load_state_dict(sd, strict=False)
     return net
+
+
+def get_pose_attn_net(cfg, is_train: bool = True, **_):
+    """factory of the attention net (pose_resnet.py:323-333): ResNet-``ATTN_NUM_LAYERS`` (default 18)"""
+    net = PoseResAttnNet(cfg, int(cfg.get("ATTN_NUM_LAYERS", 18)))
+    _load_pretrained(net.backbone, cfg, is_train)
+    return net
+
+
+def get_pose_net(cfg, is_train: bool = True, **_):
+    """factory with the reference's name/signature (pose_resnet.py:274-284); loads
+    cfg.NETWORK.PRETRAINED when the file exists (ImageNet/COCO initialisation)."""
+    return _load_pretrained(PoseResNet(cfg), cfg, is_train)

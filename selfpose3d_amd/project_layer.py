@@ -12,6 +12,7 @@ tensors must live on the GPU and libsp3d.so must be built, otherwise this raises
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Sequence
 
 import numpy as np
@@ -31,6 +32,8 @@ _PACK_CACHE: "list[tuple]" = []
 
 def packed_heatmaps(hms: Sequence[torch.Tensor], jp: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     import weakref
+    if any(h.is_inference() for h in hms):      # inference tensors carry no version counter: nothing to key on
+        return _lib.pack_heatmaps([x.detach() for x in hms], jp=jp, out_dtype=dtype)
     for refs, versions, cjp, packed in _PACK_CACHE:
         if cjp == (jp, dtype) and len(refs) == len(hms) and \
                 all(r() is h and v == h._version for r, v, h in zip(refs, versions, hms)):
@@ -117,6 +120,19 @@ class ProjectLayer(nn.Module):
         self.cache_packs = True       # share the re-tiled heat-maps between the projections of one forward
         self._cam_key = None
         self._cam_dev = None
+        self._static_cam = None       # see static_camera_table()
+
+    @contextlib.contextmanager
+    def static_camera_table(self, table: torch.Tensor):
+        """Inside the context every call uses ``table`` (a device tensor the caller refreshes itself) and re-tiles
+        the heat-maps on every call: what HIP-graph capture of a forward needs (graphs.py).  Everything is restored
+        on exit, so eager calls after a capture behave as before."""
+        prev = (self._static_cam, self.cache_packs)
+        self._static_cam, self.cache_packs = table, False
+        try:
+            yield self
+        finally:
+            self._static_cam, self.cache_packs = prev
 
     @staticmethod
     def jp_for(J: int) -> int:
@@ -127,6 +143,8 @@ class ProjectLayer(nn.Module):
         """(B,V,32) fp32 table on `device`; rebuilt only when `meta` / flip change.  The upload is one
         asynchronous copy from a small ring of pinned staging buffers (no host<->GPU synchronisation,
         unlike the ~6 blocking transfers per (sample, view) of the reference, transforms.py:67-72)."""
+        if self._static_cam is not None:
+            return self._static_cam
         key = (meta_cache_key(meta, flip_xcoords, self.img_size), batch, str(device))
         if key != self._cam_key:
             tab = torch.from_numpy(pack_cameras(meta, batch, self.img_size, flip_xcoords))

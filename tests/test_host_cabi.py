@@ -100,8 +100,18 @@ def test_camera_table_fields_and_cache_key():
     assert np.allclose(A, [[a, 0, img[0] / 2 - a * 960.0], [0, a, img[1] / 2 - a * 540.0]], atol=1e-5)
     k1 = meta_cache_key(meta, flip, img)
     assert k1 == meta_cache_key(meta, flip, img)
-    meta[0]["scale"].mul_(1.0)          # in-place edit bumps the tensor version -> new key
-    assert k1 != meta_cache_key(meta, flip, img)
+    # the key is the CONTENT of what pack_cameras reads: a value-preserving edit keeps it, any value change - also of
+    # a numpy entry edited in place, or of a new object at a recycled address - changes it
+    meta[0]["scale"].mul_(1.0)
+    assert k1 == meta_cache_key(meta, flip, img)
+    meta[1]["camera"]["fx"] = meta[1]["camera"]["fx"].numpy().copy()      # numpy entry, same values
+    assert k1 == meta_cache_key(meta, flip, img)
+    meta[1]["camera"]["fx"][2] += 1.0                                     # in-place numpy edit
+    k2 = meta_cache_key(meta, flip, img)
+    assert k2 != k1
+    meta[0]["scale"].mul_(1.01)
+    assert meta_cache_key(meta, flip, img) not in (k1, k2)
+    assert meta_cache_key(meta, ~flip, img) != meta_cache_key(meta, flip, img)
 
 
 def test_centers_valid_follow_reference_rules():

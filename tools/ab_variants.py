@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--variants", type=str, default="8,12,24,28")
+    ap.add_argument("--variants", type=str, default="24,56")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = [int(v) for v in args.variants.split(",")]
@@ -71,6 +71,10 @@ def main():
         for v in variants:
             fns[f"nhwc_v{v}"] = (lambda v=v: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J,
                                                                 h, w, cube, gs, img, False, variant=v))
+            # channels-last result (all 16 packed channels: the layout MIOpen is fed)
+            fns[f"nhwc_v{v}_cl"] = (lambda v=v: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16,
+                                                                   h, w, cube, gs, img, False, variant=v,
+                                                                   channels_last=True))
         packed16 = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
         views16 = [packed16[c] for c in range(V)]
         fns["nhwc_bf16_in"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rotate", type=int, default=1, help="number of distinct input sets cycled through")
     ap.add_argument("--planar", action="store_true")
+    ap.add_argument("--cl", action="store_true", help="channels-last result (16 channels)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = WORKLOADS[args.workload]
@@ -55,7 +56,10 @@ def main():
             _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
         else:
             _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
-                               cube, gs, img, False, variant=None if args.variant < 0 else args.variant)
+                               cube, gs, img, False, variant=None if args.variant < 0 else args.variant) if not args.cl else \
+                _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w,
+                                   cube, gs, img, False, variant=None if args.variant < 0 else args.variant,
+                                   channels_last=True)
     torch.cuda.synchronize()
     print("done", args.workload, args.variant, args.iters)
 

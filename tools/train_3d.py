@@ -17,7 +17,7 @@ import torch
 from _common import load_checkpoint, make_loader, save_checkpoint, setup
 from selfpose3d_amd import distributed as D
 from selfpose3d_amd.engine import train_3d, validate_3d
-from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+from selfpose3d_amd.models import get_multi_person_pose_net, is_ssv
 
 logger = logging.getLogger("train_3d")
 
@@ -45,6 +45,11 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "train")
+    if is_ssv(cfg) or cfg.get("WITH_SSV", False):
+        raise NotImplementedError(
+            f"{args.cfg}: MODEL {cfg.MODEL} / WITH_SSV - the self-supervised training loop (reference "
+            "lib/core/function.py:28-216, multi_person_posenet_ssv.py:197-501) is not built in this repo; only SSV "
+            "inference is (tools/validate_3d.py --with-ssv).  Refusing to train a different model under this config.")
     train_loader = make_loader(cfg, args.frames, int(cfg.TRAIN.BATCH_SIZE), rank, world, seed=1,
                                shuffle=bool(cfg.TRAIN.SHUFFLE))
     test_loader = make_loader(cfg, max(world, args.frames // 4), int(cfg.TEST.BATCH_SIZE), rank, world, seed=2,

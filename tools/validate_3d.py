@@ -10,7 +10,7 @@ import torch
 
 from _common import make_loader, setup
 from selfpose3d_amd.engine import validate_3d
-from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+from selfpose3d_amd.models import get_multi_person_pose_net, is_ssv
 
 
 def main():
@@ -23,7 +23,10 @@ def main():
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "validate")
     loader = make_loader(cfg, args.frames, int(cfg.TEST.BATCH_SIZE), rank, world, seed=2, shuffle=False)
-    model = get_multi_person_pose_net(cfg, is_train=False).to(device)
+    model = get_multi_person_pose_net(cfg, is_train=False).to(device)          # dispatch on cfg.MODEL
+    if args.with_ssv != is_ssv(cfg):
+        raise SystemExit(f"--with-ssv {'given' if args.with_ssv else 'not given'} but MODEL is {cfg.MODEL}: the two "
+                         "models have different call signatures (lib/core/function.py:370-390)")
     test_file = args.test_file or os.path.join(out, str(cfg.TEST.MODEL_FILE))
     if os.path.isfile(test_file):
         logging.info(f"=> load models state {test_file}")
