@@ -172,7 +172,16 @@ class CuboidProposalNetSoft(nn.Module):
             hm = (hm + self.noise_std * noise).clamp_(0, 1)
         return list(hm.unbind(0))
 
+    def seed_sampler(self, base_seed: int, rank: int | None = None):
+        """Give the synthetic-root sampler its own per-rank stream: with one process per GPU every rank would
+        otherwise draw the SAME roots from identically seeded global RNGs (the reference's DataParallel threads
+        share one process RNG, cuboid_proposal_net_soft.py:155-160, so its replicas differ by construction)."""
+        from .distributed import rank_generator
+        self.generator = rank_generator(base_seed, rank)
+        return self
+
     def train_rootnet(self, batch_size, meta, pred_hms=None, flip_xcoords=None, generator=None):
+        generator = generator if generator is not None else getattr(self, "generator", None)
         dev = self.grid1Dx.device
         roots = self.sample_roots(batch_size, dev, generator)
         target = self.target_cubes(roots)

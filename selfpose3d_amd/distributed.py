@@ -51,15 +51,92 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
-def gather_predictions(pred: torch.Tensor) -> torch.Tensor:
-    """all-gather per-rank predictions (B_r, ...) back into frame order (evaluation only)"""
+def gather_predictions(pred: torch.Tensor, num_frames: int | None = None) -> torch.Tensor:
+    """all-gather per-rank predictions (B_r, ...) back into frame order (evaluation only).  Shards may be uneven
+    (``shard_frames`` does not pad: with 7 frames on 2 ranks rank 0 holds 4, rank 1 holds 3): counts are exchanged
+    first, every rank pads to the largest shard, and the padding is dropped while de-interleaving."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return pred
     world = dist.get_world_size()
-    parts = [torch.empty_like(pred) for _ in range(world)]
-    dist.all_gather(parts, pred.contiguous())
-    out = torch.stack(parts, dim=1)                 # (B_r, world, ...): frame f = i*world + r
-    return out.reshape(-1, *pred.shape[1:])
+    n = torch.tensor([pred.shape[0]], dtype=torch.int64, device=pred.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    padded = pred.contiguous()
+    if padded.shape[0] < m:
+        padded = torch.cat([padded, padded.new_zeros((m - padded.shape[0],) + tuple(pred.shape[1:]))], 0)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    total = sum(counts) if num_frames is None else int(num_frames)
+    out = pred.new_empty((total,) + tuple(pred.shape[1:]))
+    for r in range(world):                          # rank r holds frames r, r+world, ...
+        out[r::world][:counts[r]] = parts[r][:counts[r]]
+    return out
+
+
+def sum_over_ranks(*values: float, device=None):
+    """all-reduce(SUM) of a few python numbers (evaluation counters: every rank must score the WHOLE set)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tuple(float(v) for v in values)
+    t = torch.tensor(values, dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tuple(float(v) for v in t.tolist())
+
+
+def barrier_sync(device=None):
+    """barrier + device synchronise: both sides of a timed region (bench.py contract)"""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_steps(step, steps: int, warmup: int, device=None):
+    """bench.py's timing rule as a function: `warmup` untimed steps, then EXACTLY `steps` steps between two
+    barrier+synchronise points; returns (seconds of the slowest rank, last step's output)."""
+    import time
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier_sync(device)
+    return max_over_ranks(time.perf_counter() - t0, device), out
+
+
+def job_throughput(units_per_rank_per_step: int, steps: int, seconds: float, world: int) -> float:
+    """whole-job units/s under weak scaling: every rank processes its own `units_per_rank_per_step`"""
+    return world * units_per_rank_per_step * steps / seconds
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    """distinct, reproducible stream per rank (augmentation, synthetic-root sampling: identical draws on every rank
+    would make N GPUs train on N copies of one sample)"""
+    return (int(base_seed) * 1_000_003 + 7919 * (int(rank) + 1)) % (2 ** 31 - 1)
+
+
+def rank_generator(base_seed: int, rank: int | None = None) -> torch.Generator:
+    r = env_world()[0] if rank is None else rank
+    return torch.Generator().manual_seed(rank_seed(base_seed, r))
+
+
+def needs_find_unused(cfg) -> bool:
+    """Does the stage this config trains leave parameters of the wrapped model without gradients?  (DDP then has to
+    walk the autograd graph every step.)  Follows the stage flags of the reference's tools/train_3d.py:48-75: frozen
+    sub-nets have requires_grad=False and are no problem; parameters that REQUIRE grad but are not reached are -
+    the root net when proposals come from ground truth (USE_GT) and the 3D nets in a 2D-only stage are simply not
+    constructed / not called, and the pose net is skipped on iterations without a valid proposal."""
+    net = cfg.NETWORK
+    if net.get("TRAIN_ONLY_2D", False):
+        return False                     # only the backbone exists and it is always reached
+    if net.get("TRAIN_ONLY_ROOTNET", False):
+        return False                     # pose net frozen, root net always reached
+    return True                          # pose net trains: an iteration without valid proposals reaches none of it
 
 
 def wrap_ddp(model: torch.nn.Module, device: torch.device | None = None, find_unused: bool = True):

@@ -121,6 +121,8 @@ def validate_3d(config, model, loader, epoch=0, output_dir=None, with_ssv=False,
             V, B = len(inputs), inputs[0].size(0)
             logger.info(f"Test: [{i}/{len(loader)}]\tTime: {bt.val:.3f}s ({bt.avg:.3f}s)\t"
                         f"Speed: {V * B / max(bt.val, 1e-9):.1f} samples/s ({B / max(bt.val, 1e-9):.1f} frames/s)")
+    from . import distributed as D
+    matched, total = D.sum_over_ranks(matched, total, device=device if device.type == "cuda" else None)   # score ALL shards
     recall = matched / max(1, total)
-    logger.info(f"root recall@150mm on synthetic frames: {recall:.4f} ({matched}/{total})")
+    logger.info(f"root recall@150mm on synthetic frames: {recall:.4f} ({int(matched)}/{int(total)})")
     return recall

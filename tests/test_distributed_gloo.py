@@ -31,9 +31,39 @@ def _worker(rank, world, port, q):
     assert sorted(sum(allf, [])) == list(range(7))
     # 2. slowest rank defines the job time
     assert D.max_over_ranks(1.0 + rank) == float(world)
-    # 3. predictions come back in frame order
+    # 3. predictions come back in frame order, also from UNEVEN shards (7 frames on 2 ranks: 4 + 3, no padding)
     pred = torch.tensor([[float(f)] for f in D.shard_frames(6, rank, world)])
     assert D.gather_predictions(pred).flatten().tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    pred7 = torch.tensor([[float(f), 10.0 * f] for f in D.shard_frames(7, rank, world)])
+    got7 = D.gather_predictions(pred7)
+    assert got7.shape == (7, 2) and got7[:, 0].tolist() == [float(f) for f in range(7)]
+    assert got7[:, 1].tolist() == [10.0 * f for f in range(7)]
+    # 3b. evaluation counters are summed over ranks; the bench timing rule runs exactly `steps` timed steps per rank,
+    #     reports the slowest rank, and the whole-job rate counts every rank's units
+    assert D.sum_over_ranks(1 + rank, 10) == (3.0, 20.0)
+    calls = []
+
+    def stub_step():
+        calls.append(1)
+        import time as _t
+        _t.sleep(0.01 * (1 + rank))
+        return len(calls)
+    secs, last = D.timed_steps(stub_step, steps=3, warmup=2)
+    assert len(calls) == 5 and last == 5
+    assert 0.06 <= secs < 0.5                          # rank 1 sleeps 20 ms per step: both ranks report >= 60 ms
+    assert D.job_throughput(4, 3, secs, world) == world * 4 * 3 / secs
+    # 3c. per-rank random streams: the synthetic-root sampler draws different roots on every rank
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net_soft import CuboidProposalNetSoft
+    cfg = load_config(None, NETWORK__ROOTNET_ROOTHM=True, NETWORK__ROOTNET_TRAIN_SYNTH=True,
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[8, 8, 4])
+    soft = CuboidProposalNetSoft(cfg).seed_sampler(123)
+    roots = soft.sample_roots(2, torch.device("cpu"), soft.generator)
+    allr = [None] * world
+    dist.all_gather_object(allr, roots.flatten()[:6].tolist())
+    assert allr[0] != allr[1]
+    again = CuboidProposalNetSoft(cfg).seed_sampler(123)
+    assert torch.equal(again.sample_roots(2, torch.device("cpu"), again.generator), roots)      # reproducible per rank
     # 4. DDP grads == grads of the mean loss over the global batch (identical replicas)
     torch.manual_seed(0)
     net = V2VNet(2, 1)
@@ -70,8 +100,20 @@ def test_two_rank_gloo_path():
     assert set(errs) == {0, 1} and max(errs.values()) < 1e-6
 
 
+def test_find_unused_follows_the_stage_flags():
+    from selfpose3d_amd import distributed as D
+    from selfpose3d_amd.config import load_config
+    assert D.needs_find_unused(load_config(None)) is True                                  # pose-net stage
+    assert D.needs_find_unused(load_config(None, NETWORK__TRAIN_ONLY_2D=True)) is False
+    assert D.needs_find_unused(load_config(None, NETWORK__TRAIN_ONLY_ROOTNET=True)) is False
+    assert D.rank_seed(5, 0) != D.rank_seed(5, 1) and D.rank_seed(5, 1) == D.rank_seed(5, 1)
+
+
 def test_single_process_helpers_are_noops():
     from selfpose3d_amd import distributed as D
+    assert D.sum_over_ranks(2, 3) == (2.0, 3.0)
+    secs, last = D.timed_steps(lambda: 7, steps=2, warmup=1)
+    assert last == 7 and secs >= 0.0
     assert D.shard_frames(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(2.5) == 2.5
     t = torch.arange(4.0)

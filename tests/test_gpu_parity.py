@@ -711,3 +711,31 @@ def test_upsample2x_gemm_scatter(dev, shape):
     ref = (F.conv_transpose3d(x.double(), w.double(), stride=2) + shift.double().view(1, O, 1, 1, 1)).clamp_min(0) + skip.double()
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
     assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["unproj_coarse_small", "unproj_coarse_j1_v1", "unproj_coarse_full_96x72",
+                                  "unproj_coarse_full_240x128", "unproj_stress_v10", "unproj_people_coarse"])
+def test_shared_rig_records_path_bit_identical(dev, name):
+    """K1 (tap records once per rig) + K2 (gather per sample) == the fused kernel, bit for bit, planar and channels-last"""
+    from selfpose3d_amd import _lib
+    case = gio.Case(name)
+    assert np.array_equal(case.cam, np.repeat(case.cam[:1], case.B, 0))          # these goldens are single-rig batches
+    base, _ = _hip_fwd(case, dev, "nhwc", want_grids=False)
+    hms = [h.to(dev) for h in case.hms]
+    cam = torch.from_numpy(case.cam).to(dev)
+    centers = torch.from_numpy(case.centers).to(dev)
+    valid = torch.from_numpy(case.valid).to(dev)
+    w, h = case.hm
+    jp = 4 if case.J <= 4 else (8 if case.J <= 8 else (12 if case.J <= 12 else 16))
+    packed = _lib.pack_heatmaps(hms, jp=jp)
+    views = [packed[c] for c in range(case.V)]
+    rec = _lib.build_records(cam[0], centers[0], case.V, jp, h, w, case.cube, case.grid_size, case.img)
+    got = _lib.unproject_fwd_records(views, jp, rec, valid, case.B, case.J, h, w, case.cube)
+    assert torch.equal(got, base)
+    got_cl = _lib.unproject_fwd_records(views, jp, rec, valid, case.B, jp, h, w, case.cube, channels_last=True)
+    assert got_cl.is_contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(got_cl[:, :case.J], base) and torch.count_nonzero(got_cl[:, case.J:]) == 0
+    # a skipped sample stays zero
+    valid0 = valid.clone(); valid0[-1] = 0
+    got0 = _lib.unproject_fwd_records(views, jp, rec, valid0, case.B, case.J, h, w, case.cube)
+    assert torch.count_nonzero(got0[-1]) == 0 and (case.B == 1 or torch.equal(got0[:-1], base[:-1]))

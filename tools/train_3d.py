@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "train")
+    torch.manual_seed(D.rank_seed(int(cfg.get("SEED", 0)), rank))       # per-rank streams (sampling, augmentation)
     if is_ssv(cfg) or cfg.get("WITH_SSV", False):
         raise NotImplementedError(
             f"{args.cfg}: MODEL {cfg.MODEL} / WITH_SSV - the self-supervised training loop (reference "
@@ -60,7 +61,7 @@ def main():
     params = select_trainable(model, cfg)
     optimizer = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
     start, best, last = (load_checkpoint(model, optimizer, out) if cfg.TRAIN.RESUME else (int(cfg.TRAIN.BEGIN_EPOCH), 0.0, -1))
-    ddp = D.wrap_ddp(model, device, find_unused=True)
+    ddp = D.wrap_ddp(model, device, find_unused=D.needs_find_unused(cfg))
     sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, list(cfg.TRAIN.LR_STEP), float(cfg.TRAIN.LR_FACTOR),
                                                  last_epoch=last)
     for epoch in range(start, int(cfg.TRAIN.END_EPOCH)):
