@@ -8,9 +8,16 @@ Workload (BASELINE.json configs[1], the config the metric is quoted on):
   One "step" = one such forward over one batch.  Multi-GPU = one process per GPU, frames sharded
   by rank (weak scaling), NO data-path collective (the path is embarrassingly parallel over frames).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the unprojection kernel: algorithmic bytes / HIP-event time vs 8 TB/s HBM peak
-  cpu_baseline - the CPU oracle (scalar C port) + torch-CPU V2V on a bounded sample of the same workload
+Heat-maps are handed over the way this repo's backbone emits them (PoseResNet.forward_views: (B,15,h,w) views of one
+channels-last (V,B,h,w,16) buffer), so the step has no re-tiling pass; `--planar-input` gives the reference's planar
+(B,15,h,w) hand-over instead (one extra pack kernel per step).  Samples 0,1 of rank 0's batch are the inputs of the
+reference golden tests/golden/rootnet_full.npz and the weights are that golden's: after the timed loop the step's own
+output is checked against the reference's root cubes and proposals (`output_check`).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with three extra objects:
+  roofline      - the unprojection kernel: algorithmic bytes / HIP-event time vs 8 TB/s HBM peak (+ path time, cold inputs)
+  cpu_baseline  - the CPU oracle (C port, OpenMP) + torch-CPU V2V on a bounded sample of the same workload, all cores and 1
+  cpu_reference - the reference's own Python timed in the build container (static: profiles/cpu_reference.json)
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -42,7 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (configs[1]: 4)")
     ap.add_argument("--roofline-iters", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-reps", type=int, default=6)
+    ap.add_argument("--cpu-baseline-reps", type=int, default=20)
     ap.add_argument("--front-conv", choices=["fft", "direct"], default="fft",
                     help="7x7x7 opening conv of V2V: frequency domain (rocFFT + sp3d_freq_contract) or MIOpen direct")
     ap.add_argument("--no-winograd", action="store_true",
@@ -50,27 +57,81 @@ def parse():
     ap.add_argument("--v2v-layout", choices=["ncdhw", "cl3d"], default="cl3d",
                     help="memory format of the V2V stack (fp32 either way)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one HIP graph")
-    ap.add_argument("--cold", action="store_true", help="also time the kernel rotating >256 MiB of inputs (MALL-cold)")
+    ap.add_argument("--no-cold", action="store_true", help="skip timing the kernel on inputs rotating through >256 MiB")
+    ap.add_argument("--planar-input", action="store_true",
+                    help="hand the heat-maps over as the reference does, planar (B,J,h,w): adds the re-tiling pass to the step")
+    ap.add_argument("--no-check", action="store_true", help="skip the reference-golden check of the step's output")
     return ap.parse_args()
 
 
-def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winograd=True):
+def golden_inputs(cfg):
+    """inputs / weights of tests/golden/rootnet_full.npz (reference CuboidProposalNet at this very size): B=2 heat-maps
+    (sample 0 uniform x0.35, sample 1 Gaussian 'people') and the deterministic parameter fill"""
     from selfpose3d_amd import synthetic as syn
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rootnet_full.npz"))
+    V, J = int(g["V"]), int(g["J"])
+    w, h = [int(v) for v in g["hm"]]
+    seed = int(g["hm_seed"])
+    rnd = syn.random_heatmaps(2, V, J, h, w, seed=seed)
+    ppl, _ = syn.people_heatmaps(2, V, J, h, w, [int(v) for v in g["img"]], seed=seed + 1)
+    return g, [torch.stack([0.35 * rnd[v][0], ppl[v][1]]) for v in range(V)]
+
+
+def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winograd=True, planar_input=False):
+    from selfpose3d_amd import _lib, synthetic as syn
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    from selfpose3d_amd.project_layer import nhwc_heatmap_views
 
     cfg = load_config(None)                         # Panoptic 5-cam defaults == the reference YAML
     V, J = int(cfg.DATASET.CAMERA_NUM), int(cfg.NETWORK.NUM_JOINTS)
     w, h = cfg.NETWORK.HEATMAP_SIZE
     meta = syn.make_meta(batch, V, cfg.NETWORK.IMAGE_SIZE)          # CPU tensors, as a DataLoader emits
-    hms = [x.to(dev) for x in syn.random_heatmaps(batch, V, J, h, w, seed=1000 + rank)]
-    torch.manual_seed(0)
-    model = CuboidProposalNet(cfg).eval().to(dev)
+    hms = syn.random_heatmaps(batch, V, J, h, w, seed=1000 + rank)
+    golden = None
+    if rank == 0 and batch >= 2:                    # samples 0,1 = the reference golden's inputs (checked after the run)
+        golden, gh = golden_inputs(cfg)
+        hms = [torch.cat([gh[v], hms[v][2:]], 0) for v in range(V)]
+    hms = [x.to(dev) for x in hms]
+    if not planar_input:                            # as PoseResNet.forward_views emits them: views of (V,B,h,w,16)
+        hms = nhwc_heatmap_views(_lib.pack_heatmaps(hms, jp=16), J)
+    model = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(model, seed=71, scale=0.05)   # non-degenerate weights (= the golden's)
+    model.eval().to(dev)
     if v2v_layout == "cl3d":
         model.use_channels_last(True)
     model.v2v_net.fft_front = front_conv == "fft"
     model.v2v_net.winograd = bool(winograd)
-    return cfg, meta, hms, model
+    return cfg, meta, hms, model, golden
+
+
+def check_output(out, golden, tol=2e-4):
+    """the step's own output (rank 0, samples 0,1) against the reference CuboidProposalNet -> V2VNet -> nms golden"""
+    from selfpose3d_amd import synthetic as syn
+    root_cubes, grid_centers = out
+    rc = root_cubes[:2].float().cpu().numpy()
+    N = rc[0].size
+    ref = golden["root_sub"]
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(rc.reshape(2, N)[:, golden["sub_idx"]] - ref).max())
+    sum_err = float(np.abs(rc.astype(np.float64).sum(axis=(1, 2, 3)) - golden["root_sum"]).max() / golden["root_abs_sum"].max())
+    vals, idx = golden["nms_vals"], golden["nms_idx"]
+    gc = grid_centers[:2].float().cpu()
+    cs = torch.tensor(syn.INITIAL_CUBE_SIZE, dtype=torch.float32)
+    gs, cen = torch.tensor(syn.SPACE_SIZE), torch.tensor(syn.SPACE_CENTER)
+    checked = bad = 0
+    for b in range(2):
+        for k in range(vals.shape[1]):
+            gap = min(abs(float(vals[b, k] - vals[b, k - 1])) if k else 9.0,
+                      abs(float(vals[b, k] - vals[b, k + 1])) if k + 1 < vals.shape[1] else 9.0)
+            if gap > 4 * tol * scale:
+                loc = torch.from_numpy(idx[b, k]).float() / (cs - 1) * gs + cen - gs / 2.0
+                checked += 1
+                bad += 0 if torch.equal(gc[b, k, :3], loc) else 1
+    ok = err <= tol * max(1.0, scale) and sum_err <= 1e-6 and bad == 0 and checked >= 10
+    return {"ok": bool(ok), "reference": "tests/golden/rootnet_full.npz (reference CuboidProposalNet, CPU fp32)",
+            "root_cubes_max_abs_err": err, "root_cubes_range": scale, "checksum_rel_err": sum_err,
+            "proposal_indices_checked": checked, "proposal_indices_wrong": bad}
 
 
 def event_time_ms(fn, iters, dev):
@@ -87,8 +148,13 @@ def event_time_ms(fn, iters, dev):
     return e0.elapsed_time(e1) / iters
 
 
-def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
+def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
+    """The dominant kernel of the unprojection as THIS step runs it (planar cubes for the frequency-domain opening
+    conv -> the 64-consecutive-voxel pipelined kernel), timed alone with HIP events on the launch stream; next to it the
+    path time (re-tiling pass included when the heat-maps arrive planar), the same kernel on inputs that rotate through
+    8 x 39 MB (MALL-cold-ish), and the other unprojection kernels of the library on the same workload."""
     from selfpose3d_amd import _lib
+    from selfpose3d_amd.project_layer import _packed_source
     B, J, h, w = hms[0].shape
     V = len(hms)
     pl = model.project_layer
@@ -96,31 +162,47 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
     centers, valid = pl.centers_valid([model.grid_center], B, dev)
     cube, gs, img = model.cube_size, model.grid_size, pl.img_size
     N = cube[0] * cube[1] * cube[2]
-    packed = _lib.pack_heatmaps(hms, jp=16)
+    src = _packed_source(hms, 16, torch.float32)
+    planar = [x.contiguous() for x in hms]
+    packed = src if src is not None else _lib.pack_heatmaps(planar, jp=16)
     views = [packed[c] for c in range(V)]
 
-    def k_nhwc():
+    def k_step_kernel():          # what the bench step launches: planar result, library default for this grid
         _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False)
 
+    def k_brick_cl():             # channels-last result (V2V without the FFT front): 4x4x4-brick kernel
+        _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
+                           channels_last=True)
+
     def k_planar():
-        _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
+        _lib.unproject_fwd(planar, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
+
+    scratch = torch.empty_like(packed)
 
     def k_pack():
-        _lib.pack_heatmaps(hms, jp=16, out=packed)
+        _lib.pack_heatmaps(planar, jp=16, out=scratch)
 
-    t_nhwc = event_time_ms(k_nhwc, iters, dev)
+    t_k = event_time_ms(k_step_kernel, iters, dev)
+    t_brick = event_time_ms(k_brick_cl, iters, dev)
     t_planar = event_time_ms(k_planar, max(10, iters // 10), dev)
     t_pack = event_time_ms(k_pack, iters, dev)
     # algorithmic bytes per launch: read every heat-map element once, write cubes
     # once; `grids` is not requested by the root net so its 3N term is dropped.
     alg_bytes = 4.0 * B * (V * J * h * w + J * N)
-    achieved = alg_bytes / (t_nhwc * 1e-3) / 1e9
+    achieved = alg_bytes / (t_k * 1e-3) / 1e9
+    path = t_k + (t_pack if planar_input else 0.0)
     out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "sp3d::unproject_pipe_kernel<16,true,1>", "kernel_us": round(t_nhwc * 1e3, 2),
+        "kernel": "sp3d::unproject_pipe_kernel<16,true,1,false,float,float>", "kernel_us": round(t_k * 1e3, 2),
         "algorithmic_bytes": int(alg_bytes),
+        "path_us": round(path * 1e3, 2),
+        "path": "unprojection kernel only: the heat-maps arrive as views of the backbone's channels-last buffer"
+                if not planar_input else "re-tiling pass (pack_nhwc_kernel<16>) + unprojection kernel: planar hand-over",
+        "path_frac": round(alg_bytes / (path * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "path_us_planar_handover": round((t_k + t_pack) * 1e3, 2),
         "other_kernels_us": {"pack_nhwc_kernel<16>": round(t_pack * 1e3, 2),
+                             "unproject_brick_kernel<16,true> (channels-last result)": round(t_brick * 1e3, 2),
                              "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},
         "timing": f"HIP events on the launch stream, {iters} back-to-back launches, inputs L2/MALL-warm",
     }
@@ -135,7 +217,7 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
             pass
     if cold:
         nset = 8
-        sets = [_lib.pack_heatmaps([torch.rand_like(x) for x in hms], jp=16) for _ in range(nset)]
+        sets = [_lib.pack_heatmaps([torch.rand_like(x) for x in planar], jp=16) for _ in range(nset)]
         state = {"i": 0}
 
         def k_cold():
@@ -143,41 +225,68 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, cold=False):
             state["i"] += 1
             _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube,
                                gs, img, False)
-        out["kernel_us_rotating_inputs"] = round(event_time_ms(k_cold, iters, dev) * 1e3, 2)
+        t_cold = event_time_ms(k_cold, iters, dev)
+        out["kernel_us_rotating_inputs"] = round(t_cold * 1e3, 2)
+        out["frac_rotating_inputs"] = round(alg_bytes / (t_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out
 
 
 def cpu_baseline_leg(cfg, meta, hms, model, reps):
-    """CPU port of the same step on the host cores of this box: scalar C oracle for the unprojection
-    and NMS (1 thread) + the V2V stack on torch-CPU pinned to 1 thread.  Bounded sample: `reps`
-    batches of the bench workload.  This is the checker's code timed as a baseline - it is never
-    on the product path."""
+    """CPU port of the same step on the host cores of this box: C oracle (OpenMP over voxels) for the unprojection
+    and NMS + the V2V stack on torch-CPU, once on ALL cores (the headline `value`) and once pinned to 1 thread.
+    Bounded sample: `reps` batches of the bench workload per setting.  This is the checker's code timed as a baseline -
+    it is never on the product path."""
     from oracle import oracle
     from selfpose3d_amd.camera_pack import pack_cameras
     B = hms[0].shape[0]
-    V = len(hms)
     pl = model.project_layer
     cam = pack_cameras(meta, B, pl.img_size)
     centers = np.repeat(np.asarray([model.grid_center], np.float32), B, 0)
     valid = np.ones(B, np.uint8)
-    hnp = [x.cpu().numpy() for x in hms]
+    hnp = [x.contiguous().cpu().numpy() for x in hms]
     import copy
-    v2v = copy.deepcopy(model.v2v_net).cpu().eval()
+    v2v = copy.deepcopy(model.v2v_net).cpu().eval().to(memory_format=torch.contiguous_format)
     nthr = torch.get_num_threads()
-    torch.set_num_threads(1)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        cubes, _ = oracle.unproject_fwd(hnp, cam, centers, valid, model.grid_size, model.cube_size, pl.img_size,
-                                        want_grids=False)
-        with torch.no_grad():
-            root = v2v(torch.from_numpy(cubes)).squeeze(1).numpy()
-        oracle.nms_topk(np.ascontiguousarray(root), 10)
-    dt = time.perf_counter() - t0
+    host = os.cpu_count() or 1
+    # torch-CPU convolutions stop scaling (and collapse: 0.2 samples/s on 256 threads vs 2.2 on one) far below the
+    # 256 hardware threads of the GPU boxes: the multi-thread run uses at most 32
+    cores = min(host, 32)
+    runs = {}
+    for threads, n in ((cores, reps), (1, max(1, reps // 3))):
+        torch.set_num_threads(threads)
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            cubes, _ = oracle.unproject_fwd(hnp, cam, centers, valid, model.grid_size, model.cube_size, pl.img_size,
+                                            want_grids=False)
+            with torch.no_grad():
+                root = v2v(torch.from_numpy(cubes)).squeeze(1).numpy()
+            oracle.nms_topk(np.ascontiguousarray(root), 10)
+        dt = time.perf_counter() - t0
+        runs[threads] = (n * B / dt, dt, n)
     torch.set_num_threads(nthr)
-    return {"value": round(reps * B / dt, 4), "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} batches of {B} frames of the bench workload ({dt:.1f} s): oracle/sp3d_oracle.c "
-                      f"unprojection + NMS (scalar C) and torch-CPU V2V, 1 thread",
-            "host_cpus": os.cpu_count()}
+    oracle.set_threads(cores)
+    return {"value": round(runs[cores][0], 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{runs[cores][2]} batches of {B} frames of the bench workload on {cores} threads ({runs[cores][1]:.1f} s) "
+                      f"and {runs[1][2]} on 1 thread ({runs[1][1]:.1f} s): oracle/sp3d_oracle.c unprojection + NMS "
+                      f"(C, OpenMP over voxels) and torch-CPU V2V",
+            "value_1_thread": round(runs[1][0], 4), "host_cpus": host}
+
+
+def cpu_reference_record():
+    """the reference's own Python on CPU, timed in the build container by tools/time_reference_cpu.py (the reference
+    cannot travel to the GPU box): static record, host described inside"""
+    f = os.path.join(ROOT, "profiles", "cpu_reference.json")
+    if not os.path.exists(f):
+        return None
+    rec = json.load(open(f))
+    c1 = rec["configs"].get("configs[1] B=4 960x512->240x128", {})
+    allc = c1.get(f"threads_{rec['host']['logical_cpus']}", {})
+    return {"value": allc.get("frames_per_s"), "unit": "samples/s", "kind": "reference", "cores": rec["host"]["logical_cpus"],
+            "value_1_thread": c1.get("threads_1", {}).get("frames_per_s"),
+            "sample": "reference CuboidProposalNet.forward (lib/models/cuboid_proposal_net.py:102-122) on configs[1] inputs, "
+                      "median of 5 after 2 warm-ups, measured in the build container, NOT on this box",
+            "host": rec["host"], "detail": c1, "source": "profiles/cpu_reference.json (tools/time_reference_cpu.py)"}
 
 
 def main():
@@ -196,13 +305,14 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     torch.backends.cudnn.benchmark = True
-    cfg, meta, hms, model = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv, not args.no_winograd)
+    cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
+                                                   not args.no_winograd, args.planar_input)
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
     def eager_step():
         # every step is a FRESH batch: drop the per-batch caches (re-tiled heat-maps, camera table) so the
-        # timed region contains the host camera pack + upload, the pack kernel and the unprojection
+        # timed region contains the host camera pack + upload, the pack kernel (planar hand-over) and the unprojection
         clear_pack_cache()
         model.project_layer._cam_key = None
         with torch.no_grad():
@@ -221,27 +331,14 @@ def main():
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             step, mode = eager_step, "eager"
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)      # the job is as slow as its slowest rank
+    # W untimed warm-up steps, then EXACTLY K steps between two barrier+synchronise points, slowest rank counts
+    elapsed, out = D.timed_steps(step, args.steps, args.warmup, dev)
 
-    result = None
     if rank == 0:
         B = args.batch
         V, J = len(hms), hms[0].shape[1]
-        value = world * B * args.steps / elapsed
+        value = D.job_throughput(B, args.steps, elapsed, world)
+        handover = "planar (B,J,h,w) -> pack(HIP) -> " if args.planar_input else "channels-last views of the backbone's buffer -> "
         result = {
             "metric": "multi-view samples/sec (5-view Panoptic, 80x80x20 voxel)",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -251,19 +348,27 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
                        "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
                        "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
-                       "step": "heat-maps(HBM) -> pack+unproject(HIP) -> V2V(fp32: 7^3 opening conv " +
+                       "step": "heat-maps(HBM, " + handover + "unproject(HIP) -> V2V(fp32: 7^3 opening conv " +
                                ("rocFFT+HIP contraction" if args.front_conv == "fft" else "MIOpen direct") +
-                               (", wide low-res 3^3 convs Winograd F(2,3) (HIP transforms + rocBLAS)" if not args.no_winograd else "") +
-                               ", other convs MIOpen) -> NMS/top-k(HIP)",
+                               (", 3^3 convs Winograd F(2,3) (fused MFMA kernel / HIP transforms + rocBLAS)" if not args.no_winograd else "") +
+                               ", other convs GEMM/MIOpen) -> NMS/top-k(HIP)",
+                       "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
+                       "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
         }
-        result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, cold=args.cold)
+        if golden is not None and not args.no_check:
+            result["output_check"] = check_output(out, golden)
+        result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, args.planar_input,
+                                          cold=not args.no_cold)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(cfg, meta, hms, model, args.cpu_baseline_reps)
         else:
             result["cpu_baseline"] = None
+        result["cpu_reference"] = cpu_reference_record()
         print(json.dumps(result), flush=True)
+        if "output_check" in result and not result["output_check"]["ok"]:
+            raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

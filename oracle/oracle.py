@@ -37,6 +37,11 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> int:
+    """OpenMP threads of the oracle's voxel loops (results do not depend on it); returns the previous setting"""
+    return int(lib().sp3d_oracle_set_threads(C.c_int(int(n))))
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 

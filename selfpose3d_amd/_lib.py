@@ -98,14 +98,6 @@ def load():
     lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
     lib.sp3d_channel_shift_act.restype = I
     lib.sp3d_channel_shift_act.argtypes = [P, P, P, I, C.c_int64, I, C.c_int64, I, V]
-    lib.sp3d_unproject_records_bytes.restype = C.c_size_t
-    lib.sp3d_unproject_records_bytes.argtypes = [I, I, I, I]
-    lib.sp3d_unproject_build_records.restype = I
-    lib.sp3d_unproject_build_records.argtypes = [P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
-    lib.sp3d_unproject_fwd_records.restype = I
-    lib.sp3d_unproject_fwd_records.argtypes = [P, I, I, P, P, P, I, I, I, I, I, I, I, I, V]
-    lib.sp3d_unproject_fwd_records_ex.restype = I
-    lib.sp3d_unproject_fwd_records_ex.argtypes = [P, I, I, P, P, P, I, I, I, I, I, I, I, I, P, I, V]
     if hasattr(lib, "sp3d_unproject_fwd_variant"):
         lib.sp3d_unproject_fwd_variant.restype = I
         lib.sp3d_unproject_fwd_variant.argtypes = [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, V]
@@ -202,47 +194,6 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
                                             int(variant) | (0x1000000 if channels_last else 0), _stream(dev))
     check(rc, "sp3d_unproject_fwd")
     return cubes, grids
-
-
-def build_records(cam_rig: torch.Tensor, center: torch.Tensor, V: int, jp: int, h: int, w: int, cube_size, grid_size,
-                  img_size, hm_bf16: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Tap records of ONE rig (cam_rig (V,32), center (3,)) for every (voxel, view): the projection half of the
-    unprojection, shared by all samples of a batch that come from the same calibrated rig and crop."""
-    lib = load()
-    _require_cuda(cam_rig, "cam_rig")
-    X, Y, Z = (int(c) for c in cube_size)
-    nbytes = int(lib.sp3d_unproject_records_bytes(V, X, Y, Z))
-    if out is None or out.numel() * 4 != nbytes:
-        out = torch.empty(nbytes // 4, dtype=torch.float32, device=cam_rig.device)
-    rc = lib.sp3d_unproject_build_records(cam_rig.data_ptr(), center.data_ptr(), out.data_ptr(), int(hm_bf16), V, jp, h, w,
-                                          X, Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]),
-                                          _stream(cam_rig.device))
-    check(rc, "sp3d_unproject_build_records")
-    return out
-
-
-def unproject_fwd_records(views: Sequence[torch.Tensor], jp: int, records: torch.Tensor, valid: torch.Tensor, B: int,
-                          J: int, h: int, w: int, cube_size, channels_last: bool = False,
-                          out_dtype: torch.dtype = torch.float32, out: Optional[torch.Tensor] = None,
-                          order: Optional[torch.Tensor] = None, xcd_chunk: int = 0) -> torch.Tensor:
-    """gather half of the shared-rig path: -> cubes (B,J,X,Y,Z) [channels_last_3d strides with ``channels_last``]"""
-    lib = load()
-    dev = records.device
-    X, Y, Z = (int(c) for c in cube_size)
-    V = len(views)
-    if out is not None:
-        cubes = out
-    elif channels_last:
-        cubes = torch.empty((B, X, Y, Z, J), dtype=out_dtype, device=dev).permute(0, 4, 1, 2, 3)
-    else:
-        cubes = torch.empty((B, J, X, Y, Z), dtype=out_dtype, device=dev)
-    flags = (OUT_CHANNELS_LAST if channels_last else 0) | (HM_BF16 if views[0].dtype == torch.bfloat16 else 0) | \
-        (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
-    rc = lib.sp3d_unproject_fwd_records_ex(_ptr_array(views), LAYOUT_NHWC | flags, jp, records.data_ptr(), valid.data_ptr(),
-                                           cubes.data_ptr(), B, V, J, h, w, X, Y, Z,
-                                           order.data_ptr() if order is not None else None, int(xcd_chunk), _stream(dev))
-    check(rc, "sp3d_unproject_fwd_records")
-    return cubes
 
 
 def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: torch.Tensor, cube_size, grid_size,

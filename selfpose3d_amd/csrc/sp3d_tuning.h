@@ -7,8 +7,9 @@
 extern "C" {
 #endif
 /* variant: bits[1:0] voxels in flight (first NHWC kernel); bit 2: no XCD-affine tile map; bit 3: pipelined
- * per-wave kernel; bit 4: one wave per workgroup; bits 17-20: log2(tiles per XCD chunk)+1; bit 24:
- * channels-last output.  Library default: 24. */
+ * per-wave kernel; bit 4: one wave per workgroup; bit 5: 4x4x4 voxel bricks per wave (workgroup = z-stack of bricks);
+ * bit 6: with bit 5, every brick its own workgroup; bits 17-20: log2(tiles per XCD chunk)+1; bit 21: plain chunk
+ * sweep; bit 24: channels-last output.  Library default: 120 (channels-last result), 56 (planar, Z % 32 == 0), else 24. */
 int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float *cam, const float *centers,
                                const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w,
                                int X, int Y, int Z, const float *grid_size, int W_in, int H_in, int variant,

@@ -795,340 +795,6 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Shared-rig path: tap records once per RIG, gather per SAMPLE.
-//
-// In inference all frames of a batch come from one calibrated rig with one crop (validate_3d.py: no
-// augmentation) and the root grid has one centre (cuboid_proposal_net.py:110), so the projection of
-// voxel n through camera c - two thirds of the kernel's VALU work - is the same for every sample.
-//   K1  build_records_kernel   one wave per 4x4x4 brick: P1 of the pipelined kernel for every view,
-//                              records {offset, 4 slot weights} stored as [brick][view][5][64] + the
-//                              voxel's view mask + a per-brick "view has taps" word
-//   K2  unproject_rec_kernel   per (sample, brick): records stream in with 5 coalesced 256-B loads per
-//                              view (through LDS into the gather mapping), then the usual 16 tap loads
-//                              + FMAs, view fusion, store.  Bit-identical to the fused kernels.
-// The host side (project_layer.py) takes this path only when every sample's camera rows and centre
-// are bit-equal; otherwise the fused kernels run.
-// ------------------------------------------------------------------------------------------
-struct RecGeom {
-    int nbx, nby, nwz;       // bricks along x, y, z
-};
-
-__host__ __device__ inline size_t rec_floats_per_brick(int V) { return (size_t)V * 320 + 64 + 64; }   // records, masks, header
-
-template <int JP, int ESZ>
-__global__ __launch_bounds__(64) void build_records_kernel(const float *__restrict__ cam, const float *__restrict__ center,
-                                                          float *__restrict__ rec, Geom g, RecGeom rg)
-{
-    const int brick = blockIdx.x;
-    const int bz = brick % rg.nwz, t = brick / rg.nwz, by = t % rg.nby, bx = t / rg.nby;
-    const int lane = threadIdx.x;
-    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-    const int vx = bx * BR + lx, vy = by * BR + ly, vz = bz * BR + lz;
-    const bool inb = vx < g.X && vy < g.Y && vz < g.Z;
-    const float x = linspace_step(g.Lx, g.stepx, g.X, min(vx, g.X - 1)) + center[0];
-    const float y = linspace_step(g.Ly, g.stepy, g.Y, min(vy, g.Y - 1)) + center[1];
-    const float z = linspace_step(g.Lz, g.stepz, g.Z, min(vz, g.Z - 1)) + center[2];
-    float *out = rec + (size_t)brick * rec_floats_per_brick(g.V);
-    int *outi = reinterpret_cast<int *>(out);
-    uint32_t mymask = 0, views = 0;
-    for (int c = 0; c < g.V; ++c) {
-        const float *cm = cam + (size_t)c * SP3D_CAM_STRIDE;
-        float y0, y1, px, py, ix, iy;
-        bool isnan;
-        proj_a(cm, x, y, z, y0, y1);
-        const bool bound = proj_b(cm, y0, y1, px, py, isnan) && inb;
-        if (bound) mymask |= (1u << c);
-        if (isnan && inb) mymask |= 0x80000000u;
-        if (!__any(bound && !isnan) && affine_finite(cm)) continue;
-        bool isnan_c = false;
-        proj_c(cm, g, px, py, ix, iy, isnan_c);
-        if (isnan_c && inb) mymask |= 0x80000000u;
-        isnan = isnan || isnan_c;
-        const bool use = bound && !isnan;
-        if (!__any(use)) continue;
-        const Rec r = make_record<JP, ESZ>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
-        const int base = c * 320 + lane;
-        outi[base] = r.off;
-        out[base + 64] = r.w00; out[base + 128] = r.w10; out[base + 192] = r.w01; out[base + 256] = r.w11;
-        views |= 1u << c;
-    }
-    outi[g.V * 320 + lane] = (int)mymask;
-    if (lane == 0) outi[g.V * 320 + 64] = (int)views;
-}
-
-// K2.  Workgroup = z-stack of `zw` bricks (planar result, as unproject_brick_kernel) or one brick (channels-last).
-template <int JP, bool OUTCL, typename TI = float, typename TO = float, int U = 4, int MINW = 4>
-__global__ __launch_bounds__(512, MINW) void unproject_rec_kernel(Views hm, const float *__restrict__ rec,
-                                                              const uint8_t *__restrict__ valid, float *__restrict__ cubes,
-                                                              Geom g, int wgs_per_sample, int nby, int nzc, int zw, int nwz,
-                                                              const int *__restrict__ order)
-{
-    constexpr int NQ = JP / 4;
-    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
-    extern __shared__ __attribute__((aligned(16))) float bsmem[];
-    int b, wg;
-    if (!xcd_map(blockIdx.x, g.B, wgs_per_sample, g.xcd_chunk, b, wg, g.xcd_order)) return;
-    if (order) wg = order[wg];          // dispatch order of a sample's workgroups (any permutation gives the same result)
-    SP3D_DIAG_FLAGS();
-    const int zc = wg % nzc, t = wg / nzc, by = t % nby, bx = t / nby;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = bx * BR, y0 = by * BR, zbase = zc * zw * BR, z0 = zbase + wave * BR;
-    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
-    float *ws = bsmem + wave * WLDS;
-    int *wsi = reinterpret_cast<int *>(ws);
-    const int g16 = lane >> 2, q = lane & 3;
-    const bool qact = q < NQ;
-    const int gy = y0 + (g16 >> 2), gz = z0 + (g16 & 3);
-    const bool ginb = gy < g.Y && gz < g.Z;
-    const int gn0 = (x0 * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);
-
-    if (!valid[b]) {
-        const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-        const int vx = x0 + lx, vy = y0 + ly, vz = z0 + lz;
-        if (vx < g.X && vy < g.Y && vz < g.Z) {
-            const int n = (vx * g.Y + vy) * g.Z + vz;
-            for (int j = 0; j < g.J; ++j)
-                Store4<TO>::store1(cb + (OUTCL ? ((size_t)n * g.J + j) : ((size_t)j * g.N + n)), 0.0f);
-        }
-        return;
-    }
-
-    if (z0 < g.Z) {
-        const int brick = (bx * nby + by) * nwz + (zc * zw + wave);
-        const float *rp = rec + (size_t)brick * rec_floats_per_brick(g.V);
-        const int *rpi = reinterpret_cast<const int *>(rp);
-        const uint32_t mymask = (uint32_t)rpi[g.V * 320 + lane];
-        uint32_t views = (uint32_t)__builtin_amdgcn_readfirstlane(rpi[g.V * 320 + 64]);
-        const int bs = g.sample_of ? g.sample_of[b] : b;
-        const uint32_t qoff = qact ? 4u * (uint32_t)sizeof(TI) * (uint32_t)q : 0u;
-        const size_t rowf = (size_t)g.w * JP;
-        float acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-        // record of the first view with taps -> registers
-        float r1, r2, r3, r4;
-        int r0;
-        int c = views ? __builtin_ctz(views) : -1;
-        if (c >= 0) {
-            const int base = c * 320 + lane;
-            r0 = rpi[base]; r1 = rp[base + 64]; r2 = rp[base + 128]; r3 = rp[base + 192]; r4 = rp[base + 256];
-        }
-        int par = 0;
-#pragma unroll 1
-        while (c >= 0) {
-            views &= views - 1;
-            const int cn = views ? __builtin_ctz(views) : -1;
-            // this view's record: registers -> LDS (gather mapping reads it back)
-            {
-                const int base = par * 320 + lane;
-                wsi[base] = r0;
-                ws[base + 64] = r1; ws[base + 128] = r2; ws[base + 192] = r3; ws[base + 256] = r4;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const char *vb = reinterpret_cast<const char *>(reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf);
-            const char *vb2 = vb + rowf * sizeof(TI);
-            const int rb = par * 320 + g16;
-#pragma unroll
-            for (int gi = 0; gi < 4 / U; ++gi) {
-                float4 t00[U], t10[U], t01[U], t11[U];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const uint32_t off = (uint32_t)wsi[rb + 16 * (gi * U + k)] + qoff;
-                    t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
-                    t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
-                    t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
-                    t11[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off) + JP);
-                }
-                if (gi == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (cn >= 0) {      // next view's record: queued behind the taps, lands while the FMAs run
-                        const int base = cn * 320 + lane;
-                        r0 = rpi[base]; r1 = rp[base + 64]; r2 = rp[base + 128]; r3 = rp[base + 192]; r4 = rp[base + 256];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int i = gi * U + k;
-                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                    float v;
-                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
-                }
-            }
-            c = cn;
-            par ^= 1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
-        const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float den = __shfl(den_l, 16 * i + g16);
-            const float rden = __shfl(rden_l, 16 * i + g16);
-            const bool vin = ginb && (x0 + i < g.X);
-            const int gn = gn0 + i * g.YZ;
-            if (OUTCL) {
-                if (qact && 4 * q < g.J && vin) {
-                    float4 o;
-                    o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
-                    o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                    if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)gn * g.J + 4 * q, o);
-                }
-            } else if (qact) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
-            }
-        }
-    }
-    if (OUTCL) return;
-    __syncthreads();
-    const float rzw = 1.0f / (float)zw;
-    const int per = 16 * zw;
-    const int jj = (int)(((float)(tid >> 4) + 0.5f) * rzw);
-    const int cw = tid - jj * per;
-    const int col = (int)(((float)cw + 0.5f) * rzw), wz = cw - col * zw;
-    const int sx = x0 + (col >> 2), sy = y0 + (col & 3), sz = zbase + wz * BR;
-    if (sx >= g.X || sy >= g.Y || sz >= g.Z) return;
-    const float *tile = bsmem + wz * WLDS + col * 4;
-    TO *dst = cb + ((size_t)sx * g.Y + sy) * g.Z + sz;
-    if ((g.Z & 3) == 0) {
-        for (int j = jj; j < g.J; j += 4) {
-            const float4 o = *reinterpret_cast<const float4 *>(tile + j * WOSTR);
-            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(dst + (size_t)j * g.N, o);
-        }
-    } else {
-        const int nz = min(BR, g.Z - sz);
-        for (int j = jj; j < g.J; j += 4)
-            for (int k = 0; k < nz; ++k) Store4<TO>::store1(dst + (size_t)j * g.N + k, tile[j * WOSTR + k]);
-    }
-}
-
-// K2, persistent form (channels-last result): a fixed grid of single-wave workgroups, each walking the virtual block
-// ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0, so a wave stays on its XCD's share of the samples).
-// No dispatch gaps between a wave's bricks, and the result stores of brick t drain while brick t+1 gathers.
-template <int JP, typename TI = float, typename TO = float, int U = 4, int MINW = 4>
-__global__ __launch_bounds__(64, MINW) void unproject_rec_persist_kernel(Views hm, const float *__restrict__ rec,
-                                                                        const uint8_t *__restrict__ valid,
-                                                                        float *__restrict__ cubes, Geom g, int wgs_per_sample,
-                                                                        int nby, int nwz, int total_vblocks)
-{
-    constexpr int NQ = JP / 4;
-    __shared__ __attribute__((aligned(16))) float ws[WREC];
-    int *wsi = reinterpret_cast<int *>(ws);
-    const int lane = threadIdx.x;
-    const int g16 = lane >> 2, q = lane & 3;
-    const bool qact = q < NQ;
-    const uint32_t qoff = qact ? 4u * (uint32_t)sizeof(TI) * (uint32_t)q : 0u;
-    const size_t rowf = (size_t)g.w * JP;
-    SP3D_DIAG_FLAGS();
-#pragma unroll 1
-    for (int vbid = blockIdx.x; vbid < total_vblocks; vbid += gridDim.x) {
-        int b, wg;
-        if (!xcd_map(vbid, g.B, wgs_per_sample, g.xcd_chunk, b, wg, g.xcd_order)) continue;
-        const int bz = wg % nwz, t = wg / nwz, by = t % nby, bx = t / nby;
-        const int x0 = bx * BR, y0 = by * BR, z0 = bz * BR;
-        TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
-        const int gy = y0 + (g16 >> 2), gz = z0 + (g16 & 3);
-        const bool ginb = gy < g.Y && gz < g.Z;
-        const int gn0 = (x0 * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);
-        if (!valid[b]) {
-            const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
-            const int vx = x0 + lx, vy = y0 + ly, vz = z0 + lz;
-            if (vx < g.X && vy < g.Y && vz < g.Z) {
-                const int n = (vx * g.Y + vy) * g.Z + vz;
-                for (int j = 0; j < g.J; ++j) Store4<TO>::store1(cb + (size_t)n * g.J + j, 0.0f);
-            }
-            continue;
-        }
-        const float *rp = rec + (size_t)wg * rec_floats_per_brick(g.V);
-        const int *rpi = reinterpret_cast<const int *>(rp);
-        const uint32_t mymask = (uint32_t)rpi[g.V * 320 + lane];
-        uint32_t views = (uint32_t)__builtin_amdgcn_readfirstlane(rpi[g.V * 320 + 64]);
-        const int bs = g.sample_of ? g.sample_of[b] : b;
-        float acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-        float r1, r2, r3, r4;
-        int r0;
-        int c = views ? __builtin_ctz(views) : -1;
-        if (c >= 0) {
-            const int base = c * 320 + lane;
-            r0 = rpi[base]; r1 = rp[base + 64]; r2 = rp[base + 128]; r3 = rp[base + 192]; r4 = rp[base + 256];
-        }
-        int par = 0;
-#pragma unroll 1
-        while (c >= 0) {
-            views &= views - 1;
-            const int cn = views ? __builtin_ctz(views) : -1;
-            {
-                const int base = par * 320 + lane;
-                wsi[base] = r0;
-                ws[base + 64] = r1; ws[base + 128] = r2; ws[base + 192] = r3; ws[base + 256] = r4;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const char *vb = reinterpret_cast<const char *>(reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf);
-            const char *vb2 = vb + rowf * sizeof(TI);
-            const int rb = par * 320 + g16;
-#pragma unroll
-            for (int gi = 0; gi < 4 / U; ++gi) {
-                float4 t00[U], t10[U], t01[U], t11[U];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const uint32_t off = (uint32_t)wsi[rb + 16 * (gi * U + k)] + qoff;
-                    t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
-                    t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
-                    t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
-                    t11[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off) + JP);
-                }
-                if (gi == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (cn >= 0) {
-                        const int base = cn * 320 + lane;
-                        r0 = rpi[base]; r1 = rp[base + 64]; r2 = rp[base + 128]; r3 = rp[base + 192]; r4 = rp[base + 256];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int i = gi * U + k;
-                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                    float v;
-                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
-                }
-            }
-            c = cn;
-            par ^= 1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
-        const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float den = __shfl(den_l, 16 * i + g16);
-            const float rden = __shfl(rden_l, 16 * i + g16);
-            const bool vin = ginb && (x0 + i < g.X);
-            const int gn = gn0 + i * g.YZ;
-            if (qact && 4 * q < g.J && vin) {
-                float4 o;
-                o.x = fuse_rcp(acc[i][0], den, rden); o.y = fuse_rcp(acc[i][1], den, rden);
-                o.z = fuse_rcp(acc[i][2], den, rden); o.w = fuse_rcp(acc[i][3], den, rden);
-                if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)gn * g.J + 4 * q, o);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // backward: lane = voxel, planar layout.  Pass 1 recomputes the pre-clamp forward value (the
 // clamp mask: grad flows where 0 <= pre <= 1, torch.clamp backward), pass 2 scatters.
 // ------------------------------------------------------------------------------------------
@@ -1378,7 +1044,18 @@ static int launch_status()
 // variant: bits[1:0] voxels in flight per lane (0:1, 1:2, 2:4); bit 2: disable the XCD-aware tile map;
 // bit 3: per-wave software-pipelined kernel (unproject_pipe_kernel); bit 4: one wave per workgroup
 // default: pipelined kernel; XCD-aware tile map only when several samples share the chip
-#define SP3D_DEFAULT_VARIANT(B) (24)
+// Default kernel per result layout and grid (profiles/r02_ab_brick.json, same-box A/B, bit-identical results):
+//   channels-last result     4x4x4 bricks, one brick per workgroup (120): -5 % on the root grid, -20 % on 64^3 person
+//                            cubes, -30 % on the 160x160x40 grid - fewer distinct 128-B lines per wave-load
+//   planar result, Z % 32==0 brick stacks of 8 (56): the workgroup store writes whole 128-B z-runs (64^3 cubes: -20 %)
+//   planar result, other Z   64 consecutive voxels per wave (24): a 20- or 40-voxel z-run does not fill store lines from a
+//                            brick stack, and the stack's barrier costs more than the gather saves (root grid: +30 %)
+static int default_variant(const Geom &g, bool out_cl)
+{
+    if (g.w < 2 || g.h < 2) return 24;
+    if (out_cl) return 120;
+    return (g.Z % 32 == 0) ? 56 : 24;
+}
 
 template <int JP>
 static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers, const uint8_t *valid, float *cubes,
@@ -1601,7 +1278,7 @@ extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_l
             hipLaunchKernelGGL(unproject_planar_kernel<16>, grid, block, 0, s, v, cam, centers, valid, cubes, grids, g);
         return launch_status();
     }
-    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, SP3D_DEFAULT_VARIANT(P), out_cl, io, s);
+    if (hm_layout == SP3D_LAYOUT_NHWC) return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, default_variant(g, out_cl), out_cl, io, s);
     return SP3D_EINVAL;
 }
 
@@ -1689,7 +1366,8 @@ extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_lay
     Views v;
     rc = load_views(v, hm_views, V);
     if (rc) return rc;
-    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, 24, (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0, 0,
+    const bool train_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, grids, g, default_variant(g, train_cl), train_cl, 0,
                        (hipStream_t)stream);
 }
 
@@ -1716,134 +1394,6 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
     case 12: hipLaunchKernelGGL((unproject_bwd2_kernel<12, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
     default: hipLaunchKernelGGL((unproject_bwd2_kernel<16, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
     }
-    return launch_status();
-}
-
-// ---- shared-rig path (see build_records_kernel) --------------------------------------------------
-extern "C" size_t sp3d_unproject_records_bytes(int V, int X, int Y, int Z)
-{
-    if (V <= 0 || X <= 0 || Y <= 0 || Z <= 0) return 0;
-    const size_t bricks = (size_t)((X + BR - 1) / BR) * ((Y + BR - 1) / BR) * ((Z + BR - 1) / BR);
-    return bricks * rec_floats_per_brick(V) * sizeof(float);
-}
-
-// cam_rig: (V,32) camera rows shared by every sample, center: (3) shared grid centre (device pointers)
-extern "C" int sp3d_unproject_build_records(const float *cam_rig, const float *center, void *records, int hm_bf16, int V,
-                                            int Jp, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
-                                            int H_in, void *stream)
-{
-    Geom g;
-    int rc = make_geom(g, 1, V, 1, h, w, X, Y, Z, grid_size, W_in, H_in);
-    if (rc) return rc;
-    if (!cam_rig || !center || !records) return SP3D_ENULL;
-    if ((Jp & 3) || Jp < 4 || Jp > 16 || w < 2 || h < 2 || (hm_bf16 && Jp != 16)) return SP3D_EUNSUPPORTED;
-    RecGeom rg{(X + BR - 1) / BR, (Y + BR - 1) / BR, (Z + BR - 1) / BR};
-    dim3 grid(rg.nbx * rg.nby * rg.nwz), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    float *rec = reinterpret_cast<float *>(records);
-#define SP3D_BR(JP_, ESZ_) hipLaunchKernelGGL((build_records_kernel<JP_, ESZ_>), grid, block, 0, s, cam_rig, center, rec, g, rg)
-    if (hm_bf16) SP3D_BR(16, 2);
-    else switch (Jp) {
-        case 4: SP3D_BR(4, 4); break;
-        case 8: SP3D_BR(8, 4); break;
-        case 12: SP3D_BR(12, 4); break;
-        default: SP3D_BR(16, 4); break;
-    }
-#undef SP3D_BR
-    return launch_status();
-}
-
-extern "C" int sp3d_unproject_fwd_records_ex(const float *const *hm_views, int hm_layout, int Jp, const void *records,
-                                             const uint8_t *valid, float *cubes, int B, int V, int J, int h, int w, int X,
-                                             int Y, int Z, const int32_t *order, int xcd_chunk, void *stream);
-
-extern "C" int sp3d_unproject_fwd_records(const float *const *hm_views, int hm_layout, int Jp, const void *records,
-                                          const uint8_t *valid, float *cubes, int B, int V, int J, int h, int w, int X,
-                                          int Y, int Z, void *stream)
-{
-    return sp3d_unproject_fwd_records_ex(hm_views, hm_layout, Jp, records, valid, cubes, B, V, J, h, w, X, Y, Z, nullptr, 0,
-                                         stream);
-}
-
-// order: optional device int32[workgroups per sample] permutation (dispatch order); xcd_chunk: 0 = default
-extern "C" int sp3d_unproject_fwd_records_ex(const float *const *hm_views, int hm_layout, int Jp, const void *records,
-                                             const uint8_t *valid, float *cubes, int B, int V, int J, int h, int w, int X,
-                                             int Y, int Z, const int32_t *order, int xcd_chunk, void *stream)
-{
-    const float gs1[3] = {1.0f, 1.0f, 1.0f};
-    Geom g;
-    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, gs1, 1, 1);
-    if (rc) return rc;
-    if (!records || !valid || !cubes) return SP3D_ENULL;
-    const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
-    const int io = ((hm_layout & SP3D_HM_BF16) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0);
-    if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || Jp < J || (Jp & 3) || Jp > 16 || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
-    if (out_cl && (J & 3)) return SP3D_EUNSUPPORTED;
-    if (io && Jp != 16) return SP3D_EUNSUPPORTED;
-    Views v;
-    rc = load_views(v, hm_views, V);
-    if (rc) return rc;
-    const int nbx = (X + BR - 1) / BR, nby = (Y + BR - 1) / BR, nwz = (Z + BR - 1) / BR;
-    int nzc = (nwz + 7) / 8, zw = (nwz + nzc - 1) / nzc;
-    if (out_cl) { zw = 1; nzc = nwz; }              // channels-last: no workgroup store, every brick on its own
-    const int wgs = nbx * nby * nzc;
-    {
-        const int xps = (g.B <= 8 && (8 % g.B) == 0) ? 8 / g.B : 1;
-        int k = 1;
-        while (k * 2 * xps * 2 <= wgs) k *= 2;
-        g.xcd_chunk = (xcd_chunk & 0xffff) > 0 ? (xcd_chunk & 0xffff) : k;
-        g.xcd_order = (g.B <= 2 && !order) ? 1 : 0;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const float *rec = reinterpret_cast<const float *>(records);
-    dim3 grid(xcd_grid_blocks(g.B, wgs, g.xcd_chunk)), block(64 * zw);
-#define SP3D_RK(JP_, CL_, TI_, TO_) do { \
-        constexpr int WLDS_ = ((JP_) * WOSTR > WREC) ? (JP_) * WOSTR : WREC; \
-        hipLaunchKernelGGL((unproject_rec_kernel<JP_, CL_, TI_, TO_>), grid, block, (size_t)zw * WLDS_ * sizeof(float), s, v, rec, valid, cubes, g, wgs, nby, nzc, zw, nwz, order); } while (0)
-    const int pers = (xcd_chunk >> 18) & 7;         // tuning: persistent K2 (channels-last, fp32, Jp 16): waves per CU = 4 * pers
-    if (pers && out_cl && !io && Jp == 16 && !order) {
-        const int total_vblocks = xcd_grid_blocks(g.B, wgs, g.xcd_chunk);
-        int nblk = 256 * 4 * pers;
-        if (nblk > total_vblocks) nblk = (total_vblocks + 7) / 8 * 8;
-        if ((xcd_chunk >> 16) & 1)
-            hipLaunchKernelGGL((unproject_rec_persist_kernel<16, float, float, 2, 5>), dim3(nblk), dim3(64), 0, s, v, rec, valid, cubes, g, wgs, nby, nwz, total_vblocks);
-        else
-            hipLaunchKernelGGL((unproject_rec_persist_kernel<16, float, float, 4, 4>), dim3(nblk), dim3(64), 0, s, v, rec, valid, cubes, g, wgs, nby, nwz, total_vblocks);
-        return launch_status();
-    }
-    const int occ = (xcd_chunk >> 16) & 3;          // tuning: 1 = U 2 / 5 waves per SIMD, 2 = U 2 / 6, 3 = U 1 / 8
-    if (occ && !io && Jp == 16) {
-#define SP3D_RKO(CL_, U_, W_) do { \
-        constexpr int WLDS_ = (16 * WOSTR > WREC) ? 16 * WOSTR : WREC; \
-        hipLaunchKernelGGL((unproject_rec_kernel<16, CL_, float, float, U_, W_>), grid, block, (size_t)zw * WLDS_ * sizeof(float), s, v, rec, valid, cubes, g, wgs, nby, nzc, zw, nwz, order); } while (0)
-        if (occ == 1) { if (out_cl) SP3D_RKO(true, 2, 5); else SP3D_RKO(false, 2, 5); }
-        else if (occ == 2) { if (out_cl) SP3D_RKO(true, 2, 6); else SP3D_RKO(false, 2, 6); }
-        else { if (out_cl) SP3D_RKO(true, 1, 8); else SP3D_RKO(false, 1, 8); }
-#undef SP3D_RKO
-        return launch_status();
-    }
-    if (io) {
-        switch (io * 2 + (out_cl ? 1 : 0)) {
-        case 2: SP3D_RK(16, false, bf16_t, float); break;
-        case 3: SP3D_RK(16, true, bf16_t, float); break;
-        case 4: SP3D_RK(16, false, float, bf16_t); break;
-        case 5: SP3D_RK(16, true, float, bf16_t); break;
-        case 6: SP3D_RK(16, false, bf16_t, bf16_t); break;
-        default: SP3D_RK(16, true, bf16_t, bf16_t); break;
-        }
-    } else {
-        switch (Jp * 2 + (out_cl ? 1 : 0)) {
-        case 8: SP3D_RK(4, false, float, float); break;
-        case 9: SP3D_RK(4, true, float, float); break;
-        case 16: SP3D_RK(8, false, float, float); break;
-        case 17: SP3D_RK(8, true, float, float); break;
-        case 24: SP3D_RK(12, false, float, float); break;
-        case 25: SP3D_RK(12, true, float, float); break;
-        case 32: SP3D_RK(16, false, float, float); break;
-        default: SP3D_RK(16, true, float, float); break;
-        }
-    }
-#undef SP3D_RK
     return launch_status();
 }
 

@@ -166,7 +166,7 @@ extern "C" int sp3d_wino_output(const float *M, float *y, const float *shift, co
 // Fused Winograd F(2x2x2, 3x3x3) for the FULL-resolution 3x3x3 layers (C = 16 or 32 -> O = 32), where the
 // transformed tensor of the three-launch form above would be 524 MB.  One wave = a block of 4x4x2 tiles (8x8x4
 // outputs x 32 channels); nothing but x, U and y touches memory:
-//   per chunk of 8 input channels: stage the 10x10x6 input region in LDS (21.6 KB);
+//   per chunk of 8 input channels: stage the 10x10x6 input region in LDS (20.2 KB, 16-byte aligned rows);
 //   per transform point: each lane builds its A operand on the fly - V[p][tile][c] is a signed sum of 8 region
 //     voxels (B^T has two non-zeros per row) - B = U[p][c][o] streams from L2, and v_mfma_f32_32x32x2_f32
 //     (tiles x outputs, K = 8 channels) accumulates;
@@ -185,8 +185,13 @@ __device__ unsigned long long *g_wf_tl = nullptr;
 
 constexpr int WF_RX = 10, WF_RY = 10, WF_RZ = 6;
 constexpr int WF_VS = 8;                       // floats per staged voxel (one chunk of 8 input channels)
-constexpr int WF_ROW = WF_RX * WF_VS + 1;      // odd row pitch: spreads the tiles' (y,z) rows over the LDS banks
-constexpr int WF_LDS = WF_RY * WF_RZ * WF_ROW; // 4 860 floats = 19.4 KB -> 8 waves per CU
+// Row pitch 84 floats: rows stay 16-byte aligned, so a lane fetches its 4 channels of a voxel with ONE ds_read_b128 (and the
+// staging writes are ds_write_b128).  With stride-2 tiles the 16 lanes of a b128 lane group can spread over only 32 of
+// the 64 banks whatever the pitch (2*tty*ROW + 2*ttz*PLANE is a multiple of 8 floats): 2-way conflicts, 8 LDS cycles per
+// instruction, 16 instructions per (j,k) step = 128 cycles - against 64 ds_read_b32 x >= 4 cycles with the former odd
+// pitch (profiles/r01_pmc_wino_fused.json: 74 % of the LDS cycles were conflicts).
+constexpr int WF_ROW = WF_RX * WF_VS + 4;
+constexpr int WF_LDS = WF_RY * WF_RZ * WF_ROW; // 5 040 floats = 20 160 B -> 8 waves per CU (161 280 of 163 840 B)
 
 // B^T rows as (first tap +, second tap, sign of second): d0-d2, d1+d2, d2-d1, d1-d3
 __device__ constexpr int wf_ta(int r) { return r == 0 ? 0 : (r == 1 ? 1 : (r == 2 ? 2 : 1)); }
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                                                        int NBY, int NBZ)
 {
     constexpr int O = 32;
-    __shared__ float region[WF_LDS];
+    __shared__ __attribute__((aligned(16))) float region[WF_LDS];
     const int lane = threadIdx.x, t = lane & 31, h = lane >> 5;
     int bid = blockIdx.x;
     const int bz = bid % NBZ; bid /= NBZ;
@@ -211,8 +216,9 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
     const int b = bid / NBX;
     const int ttx = t & 3, tty = (t >> 2) & 3, ttz = t >> 4;
     const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 4;                 // first output voxel of the block
-    // region address of (vx,vy,vz,c) = (vz*RY + vy)*ROW + vx*VS + c; this tile's patch origin, + c = 2*kk + h
-    const float *rb = region + ((2 * ttz) * WF_RY + 2 * tty) * WF_ROW + (2 * ttx) * WF_VS + h;
+    // region address of (vx,vy,vz,c) = (vz*RY + vy)*ROW + vx*VS + c; this tile's patch origin.  MFMA k-slot h of step kk
+    // carries channel kk + 4*h of the chunk, so a lane's four channels (kk = 0..3) are 16 contiguous bytes
+    const float *rb = region + ((2 * ttz) * WF_RY + 2 * tty) * WF_ROW + (2 * ttx) * WF_VS + 4 * h;
 
     f32x16 acc[8];
 #pragma unroll
@@ -248,14 +254,13 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
                 if (idx < WF_RX * WF_RY * WF_RZ * 2) {
                     const int v = idx >> 1, half = idx & 1;
                     const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
-                    float *r = region + (vz * WF_RY + vy) * WF_ROW + vx * WF_VS + half * 4;
-                    r[0] = d[u].x; r[1] = d[u].y; r[2] = d[u].z; r[3] = d[u].w;
+                    *reinterpret_cast<float4 *>(region + (vz * WF_RY + vy) * WF_ROW + vx * WF_VS + half * 4) = d[u];
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const float *ub = U + ((int64_t)(cc * 8 + h)) * O + t;             // + p*C*O + 2*kk*O
+        const float *ub = U + ((int64_t)(cc * 8 + 4 * h)) * O + t;         // + p*C*O + kk*O
         // (y,z) index of the transform point: run-time loop; x index: unrolled.  The inverse transform along x is
         // folded into the MFMA accumulation (two accumulators, A^T = [1,1,1,0] / [0,1,-1,-1] as +-A operands), the one
         // along y,z is applied once per (j,k) on the VALU with wave-uniform coefficients.
@@ -272,15 +277,17 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) bnxt[i * 4 + kk] = un[(int64_t)(i * 16) * C * O + 2 * kk * O];
+                for (int kk = 0; kk < 4; ++kk) bnxt[i * 4 + kk] = un[(int64_t)(i * 16) * C * O + kk * O];
             float g[4][4];                                                 // [x tap][kk]: y,z transform done
 #pragma unroll
-            for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int o = xi * WF_VS + 2 * kk;
-                    g[xi][kk] = fmaf(sz, fmaf(sy, r11[o], r01[o]), fmaf(sy, r10[o], r00[o]));
-                }
+            for (int xi = 0; xi < 4; ++xi) {
+                const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * WF_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * WF_VS);
+                const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * WF_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * WF_VS);
+                g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
+                g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
+                g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
+                g[xi][3] = fmaf(sz, fmaf(sy, v11.w, v01.w), fmaf(sy, v10.w, v00.w));
+            }
             if (cc == 0) WF_STAMP(8 + 4 * jk);                             // operands ready
             // wave-uniform y,z coefficients of A^T for the four (b,c) output positions
             float cyz[4];
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) b0[i * 4 + kk] = ub[(int64_t)(i * 16) * C * O + 2 * kk * O];
+            for (int kk = 0; kk < 4; ++kk) b0[i * 4 + kk] = ub[(int64_t)(i * 16) * C * O + kk * O];
 #pragma unroll 1
         for (int jk = 0; jk < 16; jk += 2) {
             step(jk, jk + 1, b0, b1);

@@ -11,6 +11,7 @@ from typing import List, Sequence
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 _BN_MOM = 0.1
 
@@ -107,22 +108,39 @@ class PoseResNet(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
-    def forward(self, x, attn: bool = False):
+    def forward(self, x, attn: bool = False, head: bool = True):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         feat = self.deconv_layers(x)
-        out = self.final_layer(feat)
+        out = self.final_layer(feat) if head else None
         return (out, feat) if attn else out
 
     def forward_views(self, views: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """list[V] of (B,3,H,W) -> list[V] of (B,J,h,w): one (V*B)-image pass instead of V passes.
-        Identical to the per-view loop whenever BatchNorm is in eval mode (running statistics)."""
+        Identical to the per-view loop whenever BatchNorm is in eval mode (running statistics).
+
+        On the GPU the 1x1 head runs with its filter bank zero-padded to ceil4(J) outputs in channels_last, so its
+        result IS the (V,B,h,w,Jp) buffer the unprojection kernel gathers from; the returned per-view tensors are
+        (B,J,h,w) views of it (``project_layer.nhwc_heatmap_views``) and the re-tiling pass disappears."""
         if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
             return [self.forward(v) for v in views]
         V, B = len(views), views[0].shape[0]
         x = torch.cat(list(views), 0).contiguous(memory_format=torch.channels_last)
-        y = self.forward(x).contiguous()
-        return list(y.view(V, B, *y.shape[1:]).unbind(0))
+        fl = self.final_layer
+        J = fl.out_channels
+        if not x.is_cuda or J > 16:
+            y = self.forward(x).contiguous()
+            return list(y.view(V, B, *y.shape[1:]).unbind(0))
+        from .project_layer import ProjectLayer, nhwc_heatmap_views
+        _, feat = self.forward(x, attn=True, head=False)
+        jp = ProjectLayer.jp_for(J)
+        wgt, bias = fl.weight, fl.bias
+        if jp != J:
+            wgt = torch.cat([wgt, wgt.new_zeros((jp - J,) + tuple(wgt.shape[1:]))], 0)
+            bias = None if bias is None else torch.cat([bias, bias.new_zeros(jp - J)], 0)
+        y = F.conv2d(feat, wgt, bias, fl.stride, fl.padding).contiguous(memory_format=torch.channels_last)
+        packed = y.permute(0, 2, 3, 1).view(V, B, y.shape[2], y.shape[3], jp)
+        return nhwc_heatmap_views(packed, J)
 
 
 class PoseResAttnNet(nn.Module):

@@ -49,6 +49,38 @@ def clear_pack_cache():
     _PACK_CACHE.clear()
 
 
+def nhwc_heatmap_views(packed: torch.Tensor, num_joints: int) -> "list[torch.Tensor]":
+    """``packed`` (V,B,h,w,Jp), channels >= num_joints ZERO  ->  list[V] of (B,J,h,w) tensors that are strided views
+    of it (no copy).  This is how a producer that already works channels-last (``PoseResNet.forward_views``: the
+    1x1 head emits 16 channels, the 16th filter being zero) hands its heat-maps over: every consumer sees the
+    reference's ``list[V] of (B,J,h,w)`` and ``ProjectLayer`` recognises the views and skips its re-tiling pass -
+    the kernel reads the producer's buffer directly (``SP3D_LAYOUT_NHWC`` takes per-view pointers)."""
+    V, B, h, w, Jp = packed.shape
+    if not packed.is_contiguous() or Jp != ProjectLayer.jp_for(num_joints):
+        raise _lib.Sp3dError(f"nhwc_heatmap_views: need a contiguous (V,B,h,w,{ProjectLayer.jp_for(num_joints)}) buffer")
+    views = []
+    for c in range(V):
+        t = packed[c].permute(0, 3, 1, 2)[:, :num_joints]
+        t._sp3d_packed = (packed, c)
+        views.append(t)
+    return views
+
+
+def _packed_source(hms: Sequence[torch.Tensor], jp: int, dtype: torch.dtype):
+    """the (V,B,h,w,jp) buffer the heat-maps are views of (see nhwc_heatmap_views), or None"""
+    tag = getattr(hms[0], "_sp3d_packed", None)
+    if tag is None:
+        return None
+    base = tag[0]
+    if base.dtype != dtype or base.shape[-1] != jp or base.shape[0] != len(hms):
+        return None
+    for c, h in enumerate(hms):
+        t = getattr(h, "_sp3d_packed", None)
+        if t is None or t[0] is not base or t[1] != c:
+            return None
+    return base
+
+
 class _UnprojectFn(torch.autograd.Function):
     """autograd seam: gradient flows to the heat-maps only."""
 
@@ -59,11 +91,16 @@ class _UnprojectFn(torch.autograd.Function):
         B = int(centers.shape[0])                 # number of output cubes (== batch unless `sample_of` is given)
         hms = [x.detach() for x in heatmaps]
         io = layer.io_dtype
-        if io == torch.float32:
+        source = _packed_source(heatmaps, layer.jp_for(J), io) if mode == "nhwc" else None
+        if io == torch.float32 and source is None:
             hms = [x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float() for x in hms]
         if mode == "nhwc":
-            packed = packed_heatmaps(heatmaps, layer.jp_for(J), io) if layer.cache_packs else \
-                _lib.pack_heatmaps(hms, jp=layer.jp_for(J), out_dtype=io)
+            if source is not None:
+                packed = source.detach()          # producer already emits (V,B,h,w,jp): no re-tiling pass
+            elif layer.cache_packs:
+                packed = packed_heatmaps(heatmaps, layer.jp_for(J), io)
+            else:
+                packed = _lib.pack_heatmaps(hms, jp=layer.jp_for(J), out_dtype=io)
             jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
             # when a gradient will be asked for, let the kernel also emit the clamp pass mask: the backward
@@ -85,7 +122,10 @@ class _UnprojectFn(torch.autograd.Function):
         ctx.layer = layer
         ctx.geom = (tuple(grid_size), tuple(cube_size))
         ctx.sample_of = sample_of
-        ctx.save_for_backward(cam, centers, valid, *hms)
+        if ctx.packed_bwd is not None:
+            ctx.save_for_backward(cam, centers, valid)        # the packed backward reads no heat-map
+        else:
+            ctx.save_for_backward(cam, centers, valid, *hms)
         if grids is None:
             grids = torch.empty(0, device=cubes.device)
         ctx.mark_non_differentiable(grids)

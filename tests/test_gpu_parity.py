@@ -713,29 +713,71 @@ def test_upsample2x_gemm_scatter(dev, shape):
     assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("name", ["unproj_coarse_small", "unproj_coarse_j1_v1", "unproj_coarse_full_96x72",
-                                  "unproj_coarse_full_240x128", "unproj_stress_v10", "unproj_people_coarse"])
-def test_shared_rig_records_path_bit_identical(dev, name):
-    """K1 (tap records once per rig) + K2 (gather per sample) == the fused kernel, bit for bit, planar and channels-last"""
+def test_nhwc_heatmap_views_skip_the_retiling_pass(dev):
+    """heat-maps handed over as (B,J,h,w) VIEWS of a channels-last (V,B,h,w,16) buffer (what PoseResNet.forward_views
+    emits) are unprojected straight from that buffer: same bits as the planar hand-over, no pack kernel, gradients too"""
     from selfpose3d_amd import _lib
-    case = gio.Case(name)
-    assert np.array_equal(case.cam, np.repeat(case.cam[:1], case.B, 0))          # these goldens are single-rig batches
-    base, _ = _hip_fwd(case, dev, "nhwc", want_grids=False)
-    hms = [h.to(dev) for h in case.hms]
-    cam = torch.from_numpy(case.cam).to(dev)
-    centers = torch.from_numpy(case.centers).to(dev)
-    valid = torch.from_numpy(case.valid).to(dev)
-    w, h = case.hm
-    jp = 4 if case.J <= 4 else (8 if case.J <= 8 else (12 if case.J <= 12 else 16))
-    packed = _lib.pack_heatmaps(hms, jp=jp)
-    views = [packed[c] for c in range(case.V)]
-    rec = _lib.build_records(cam[0], centers[0], case.V, jp, h, w, case.cube, case.grid_size, case.img)
-    got = _lib.unproject_fwd_records(views, jp, rec, valid, case.B, case.J, h, w, case.cube)
-    assert torch.equal(got, base)
-    got_cl = _lib.unproject_fwd_records(views, jp, rec, valid, case.B, jp, h, w, case.cube, channels_last=True)
-    assert got_cl.is_contiguous(memory_format=torch.channels_last_3d)
-    assert torch.equal(got_cl[:, :case.J], base) and torch.count_nonzero(got_cl[:, case.J:]) == 0
-    # a skipped sample stays zero
-    valid0 = valid.clone(); valid0[-1] = 0
-    got0 = _lib.unproject_fwd_records(views, jp, rec, valid0, case.B, case.J, h, w, case.cube)
-    assert torch.count_nonzero(got0[-1]) == 0 and (case.B == 1 or torch.equal(got0[:-1], base[:-1]))
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer, clear_pack_cache, nhwc_heatmap_views
+    for name in ("unproj_coarse_full_96x72", "unproj_fine_small", "unproj_coarse_aug"):
+        case = gio.Case(name)
+        cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+        layer = ProjectLayer(cfg)
+        gc = case.grid_center if isinstance(case.grid_center, list) else case.grid_center.to(dev)
+        planar = [h.to(dev) for h in case.hms]
+        base, grids = layer(planar, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip)
+        packed = _lib.pack_heatmaps(planar, jp=ProjectLayer.jp_for(case.J))
+        views = nhwc_heatmap_views(packed, case.J)
+        assert all(torch.equal(v, p) for v, p in zip(views, planar)) and not views[0].is_contiguous()
+        clear_pack_cache()
+        calls = []
+        orig = _lib.pack_heatmaps
+        _lib.pack_heatmaps = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        try:
+            got, g2 = layer(views, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip)
+            padded, _ = layer.get_voxel(views, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip,
+                                        want_grids=False, pad_channels=True, channels_last=True)
+        finally:
+            _lib.pack_heatmaps = orig
+        assert not calls, "the re-tiling pass must not run for NHWC views"
+        assert torch.equal(got, base) and torch.equal(g2, grids)
+        assert torch.equal(padded[:, :case.J], base) and torch.count_nonzero(padded[:, case.J:]) == 0
+    # gradients: the same scatter result whichever way the maps were handed over
+    case = gio.Case("unproj_grad_small")
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+    layer = ProjectLayer(cfg)
+    wgt = torch.from_numpy(np.random.default_rng(int(case.g["grad_seed"])).standard_normal(
+        (case.B, case.J, *case.cube)).astype(np.float32)).to(dev)
+    packed = _lib.pack_heatmaps([h.to(dev) for h in case.hms], jp=ProjectLayer.jp_for(case.J)).requires_grad_(True)
+    views = nhwc_heatmap_views(packed, case.J)
+    cubes, _ = layer(views, case.meta, case.grid_size, case.grid_center, case.cube)
+    (cubes * wgt).sum().backward()
+    gp = packed.grad.permute(0, 1, 4, 2, 3)[:, :, :case.J].cpu().numpy()            # (V,B,J,h,w)
+    ref = case.g["grad_hm"]
+    assert np.abs(gp - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert float(packed.grad[..., case.J:].abs().max()) == 0.0 if packed.shape[-1] > case.J else True
+
+
+def test_backbone_emits_unprojection_ready_heatmaps(dev):
+    """PoseResNet.forward_views on the GPU: 16-channel channels-last head, per-view (B,15,h,w) views, 16th channel zero,
+    values equal to the plain per-view forward up to conv rounding"""
+    from selfpose3d_amd import pose_resnet
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import _packed_source
+    cfg = load_config(None, POSE_RESNET__NUM_LAYERS=18)
+    net = pose_resnet.get_pose_net(cfg, is_train=False)
+    torch.manual_seed(0)
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            torch.nn.init.kaiming_normal_(m.weight)
+    net.eval().to(dev).to(memory_format=torch.channels_last)
+    views = [torch.randn(2, 3, 64, 96, device=dev) for _ in range(3)]
+    with torch.no_grad():
+        outs = net.forward_views(views)
+        ref = [net(v) for v in views]
+    src = _packed_source(outs, 16, torch.float32)
+    assert src is not None and src.shape == (3, 2, 16, 24, 16)
+    assert torch.count_nonzero(src[..., 15]) == 0
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape == (2, 15, 16, 24)
+        assert float((o - r).abs().max()) <= 1e-4 * float(r.abs().max())

@@ -75,16 +75,6 @@ def main():
             fns[f"nhwc_v{v}_cl"] = (lambda v=v: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16,
                                                                    h, w, cube, gs, img, False, variant=v,
                                                                    channels_last=True))
-        if not wl["fine"]:          # shared-rig path: records once per rig (K1), gather per sample (K2)
-            state = {}
-
-            def k1():
-                state["rec"] = _lib.build_records(cam[0], centers[0], V, 16, h, w, cube, gs, img, out=state.get("rec"))
-            k1()
-            fns["rig_records_k1"] = k1
-            fns["rig_gather_k2"] = lambda: _lib.unproject_fwd_records(views, 16, state["rec"], valid, B, J, h, w, cube)
-            fns["rig_gather_k2_cl"] = lambda: _lib.unproject_fwd_records(views, 16, state["rec"], valid, B, 16, h, w, cube,
-                                                                         channels_last=True)
         packed16 = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
         views16 = [packed16[c] for c in range(V)]
         fns["nhwc_bf16_in"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round profile set (GPU box): kernel trace of the bench command + PMC passes of the kernels DESIGN.md quotes.
+#   bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*   (copy what is judged into profiles/)
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-r02}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. bench line + kernel trace of the same command
+python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+rm -rf $O/${TAG}_trace
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o bench -- \
+    python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --roofline-iters 40 > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace.err
+python $R/tools/rocpd_stats.py $O/${TAG}_trace > $O/${TAG}_bench_kernel_stats.md 2>> $O/${TAG}_trace.err
+find $O/${TAG}_trace -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
+rm -rf $O/${TAG}_trace
+# 2. PMC: unprojection kernels on the bench workload (planar default), stress and fine configs
+cd $R
+bash tools/collect_pmc.sh $O/${TAG}_pmc_coarse_b4 coarse_b4_v5 -1 > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/${TAG}_pmc_stress_v10 stress_b1_v10 -1 > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/${TAG}_pmc_stress_v10_cl stress_b1_v10 -1 --cl > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64 fine_b10_v5 -1 > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64_v24 fine_b10_v5 24 > /dev/null 2>&1
+for d in coarse_b4 stress_v10 stress_v10_cl fine64 fine64_v24; do rm -rf $O/${TAG}_pmc_$d/pass*/; done
+# 3. PMC: fused Winograd kernel
+bash tools/pmc_wino_fused.sh > $O/${TAG}_pmc_wino_fused.txt 2>&1
+cp $O/pmc_wf/summary.json $O/${TAG}_pmc_wino_fused.json 2>/dev/null
+rm -rf $O/pmc_wf
+ls $O | grep ${TAG}
