@@ -39,6 +39,9 @@ class GraphedRootNet:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph), torch.no_grad():
                 self.out = net(self.static_hms, meta, flip_xcoords)
+        # the captured kernels read the folded inference plan's tensors by address: keep them alive even if the net
+        # drops its plan later (train() / load_state_dict / invalidate_plan)
+        self._plan = getattr(getattr(net, "v2v_net", None), "_plan", None)
 
     def __call__(self, meta=None):
         """one step: pack the (possibly new) camera table, upload it asynchronously, replay"""

@@ -183,7 +183,10 @@ class _FoldedV2V:
     preceding (transposed) conv's weights, so a layer is one MIOpen conv (no bias) + ONE fused
     in-place epilogue (sp3d_channel_shift_act: shift [+ residual] [+ ReLU]) instead of conv + bias +
     BatchNorm + ReLU (+ add) kernels.  Same math as v2v_net.py:10-110 up to fp32 rounding of the
-    folded weights.  Rebuilt whenever a parameter / buffer version, device or memory format changes."""
+    folded weights.  Rebuilt whenever any parameter / buffer was replaced, moved or written through autograd-visible ops
+    ((data_ptr, _version) of EVERY tensor), when the memory format of the 3x3x3 weights changes, after ``train()`` and
+    after ``load_state_dict``.  Writes through ``.data`` leave no trace in tensor metadata: call
+    ``V2VNet.invalidate_plan()`` after such weight surgery."""
 
     def __init__(self, net: "V2VNet"):
         self.net = net
@@ -193,9 +196,10 @@ class _FoldedV2V:
     @staticmethod
     def _key(net):
         ps = list(net.parameters()) + list(net.buffers())
-        w = net.output_layer.weight
-        return (sum(p._version for p in ps), str(w.device), w.is_contiguous(memory_format=torch.channels_last_3d),
-                tuple(id(p) for p in ps[:4]))
+        w3 = net.front_layers[1].res_branch[0].weight          # a 3x3x3 weight: its strides tell the memory format
+        # (a 1x1x1 weight is "contiguous" in both formats)
+        return (tuple((p.data_ptr(), p._version) for p in ps), str(w3.device),
+                bool(w3.is_contiguous(memory_format=torch.channels_last_3d) and not w3.is_contiguous()))
 
     @staticmethod
     def _fold(conv, bn, transposed=False):
@@ -366,6 +370,20 @@ class V2VNet(nn.Module):
             if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
                 nn.init.normal_(m.weight, 0.0, 0.001)
                 nn.init.zeros_(m.bias)
+
+    def invalidate_plan(self):
+        """drop the folded inference plan (BatchNorm-folded / Winograd / frequency-domain weights); it is rebuilt from
+        the current parameters on the next eval forward"""
+        self._plan = None
+        return self
+
+    def train(self, mode: bool = True):
+        self._plan = None                      # weights are about to change (or just did)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._plan = None
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x):
         if self.fused_inference and not self.training and not torch.is_grad_enabled() and x.is_cuda \

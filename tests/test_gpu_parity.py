@@ -82,7 +82,7 @@ def test_unproject_fwd_vs_oracle_and_golden(dev, name, layout):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 8, 12, 24, 28, 24 | (1 << 21), 24 | (1 << 17), 24 | (7 << 17),
-                                     56, 56 | (1 << 21), 56 | (1 << 17), 56 | (5 << 17)])
+                                     56, 56 | (1 << 21), 56 | (1 << 17), 56 | (5 << 17), 120, 120 | (1 << 17)])
 def test_nhwc_variants_bit_identical(dev, variant):
     case = gio.Case("unproj_coarse_full_96x72")
     base, _ = _hip_fwd(case, dev, "planar")

@@ -58,7 +58,7 @@ def test_random_case_bit_exact(idx, case):
         jp = 4 if J <= 4 else (8 if J <= 8 else (12 if J <= 12 else 16))
         packed = _lib.pack_heatmaps(d_h, jp=jp)
         views = [packed[c] for c in range(V)]
-        for variant in (None, 1, 8, 24, 56):  # default, block-synchronous, pipelined 4 waves/WG, 1 wave/WG, 4x4x4 bricks
+        for variant in (None, 1, 8, 24, 56, 120):  # default, block-synchronous, pipelined 4 waves/WG, 1 wave/WG, 4x4x4 bricks
             got, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, camd, cen, val, B, J, h, w, cube, gs, img, True,
                                             variant=variant)
             assert np.array_equal(grids.cpu().numpy(), ref_g)

@@ -259,3 +259,22 @@ def test_project_joints_matches_reference_project_pose_batch():
         got = px[:, b, :people[b]].numpy()
         scale = max(1.0, float(np.abs(ref).max()))
         assert np.abs(got - ref).max() <= 2e-5 * scale, (b, np.abs(got - ref).max())
+
+
+def test_v2v_inference_plan_key_sees_every_weight_change():
+    """the folded plan must not survive memory-format changes, in-place writes, train() or load_state_dict"""
+    from selfpose3d_amd.v2v_net import V2VNet, _FoldedV2V
+    net = V2VNet(2, 1).eval()
+    k0 = _FoldedV2V._key(net)
+    assert k0 == _FoldedV2V._key(net)
+    net.to(memory_format=torch.channels_last_3d)
+    k1 = _FoldedV2V._key(net)
+    assert k1 != k0
+    with torch.no_grad():
+        net.encoder_decoder.mid_res.res_branch[0].weight.mul_(2.0)
+    assert _FoldedV2V._key(net) != k1
+    for action in (lambda: net.train(), lambda: net.eval(), lambda: net.load_state_dict(net.state_dict()),
+                   lambda: net.invalidate_plan()):
+        net._plan = object()
+        action()
+        assert net._plan is None
