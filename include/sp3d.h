@@ -113,6 +113,19 @@ int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_layout, int 
                                const float *grid_size, int W_in, int H_in, void *stream);
 
 /*
+ * sp3d_unproject_fwd_indexed writing a PLANAR result into a larger caller-owned buffer: element (p, j, x, y, z) goes to
+ * cubes[p*s[0] + j*s[1] + x*s[2] + y*s[3] + z], `out_strides` = HOST int64[4] in elements (z is contiguous, planes must
+ * not overlap).  Everything outside the addressed elements is left untouched.  This is how the root cubes land
+ * directly inside the zero-padded input of the frequency-domain opening convolution (the consumer of
+ * cuboid_proposal_net.py:110's cubes) without a pad/copy pass.  NHWC input only, no grids, no channels-last.
+ * 16-byte stores are used when every stride is a multiple of 4 and `cubes` is 16-byte aligned.
+ */
+int sp3d_unproject_fwd_strided(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                               const int32_t *sample_of, const float *centers, const uint8_t *valid, float *cubes,
+                               const int64_t *out_strides, int P, int V, int J, int h, int w, int X, int Y, int Z,
+                               const float *grid_size, int W_in, int H_in, void *stream);
+
+/*
  * Gradient of get_voxel w.r.t. the heat-maps (autograd of project_layer.py:93-99;
  * cameras/grids never need gradients: proposals are detached, cuboid_proposal_net.py:57-59).
  *   hm_views      planar heat-maps of the forward pass (needed for the clamp mask)
@@ -146,6 +159,21 @@ int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const 
                               const float *grad_cubes, const uint16_t *pass_mask, float *grad_packed, int B, int P,
                               int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
                               int W_in, int H_in, void *stream);
+
+/*
+ * DETERMINISTIC form of sp3d_unproject_bwd_packed (the reference's grid_sampler_2d_backward and the
+ * fp32 atomics above both sum in hardware order).  Contributions are accumulated in 64-bit FIXED POINT with integer
+ * atomics - integer addition is associative, so the result is bit-identical run to run and independent of scheduling.
+ *   grad_fixed  (V,B,h,w,Jp) int64, zero-filled by the caller
+ *   scale       DEVICE float: a power of two 2^k; a contribution v is added as round(v * scale).  The caller picks k
+ *               from max|grad_cubes| so that |v * scale| <= 2^40 (2^23 contributions per pixel then still fit).
+ * sp3d_fixed_to_float(acc, out, scale, n) converts: out[i] = (float)(acc[i] / scale).
+ */
+int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                                  const float *grad_cubes, const uint16_t *pass_mask, int64_t *grad_fixed,
+                                  const float *scale, int B, int P, int V, int J, int Jp, int h, int w, int X, int Y,
+                                  int Z, const float *grid_size, int W_in, int H_in, void *stream);
+int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream);
 
 /*
  * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,

@@ -27,8 +27,8 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -98,6 +98,8 @@ def load():
     lib.sp3d_soft_argmax_grid.argtypes = [P, P, P, I, I, I, P, I, I, F, V]
     lib.sp3d_channel_shift_act.restype = I
     lib.sp3d_channel_shift_act.argtypes = [P, P, P, I, C.c_int64, I, C.c_int64, I, V]
+    lib.sp3d_unproject_fwd_strided.restype = I
+    lib.sp3d_unproject_fwd_strided.argtypes = [P, I, I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     if hasattr(lib, "sp3d_unproject_fwd_variant"):
         lib.sp3d_unproject_fwd_variant.restype = I
         lib.sp3d_unproject_fwd_variant.argtypes = [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, I, V]
@@ -156,15 +158,28 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
                   want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False,
                   sample_of: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
-                  pass_mask: Optional[torch.Tensor] = None):
+                  pass_mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
     """-> (cubes (B,J,X,Y,Z), grids (B,N,3) | None).  With ``channels_last`` the cubes tensor has
     torch.channels_last_3d strides (memory (B,X,Y,Z,J), J % 4 == 0, NHWC input only).
-    ``sample_of`` (int32, (B,)): output cube p reads heat-map/camera row sample_of[p] (B = #cubes)."""
+    ``sample_of`` (int32, (B,)): output cube p reads heat-map/camera row sample_of[p] (B = #cubes).
+    ``out``: a (B,J,X,Y,Z) VIEW of a larger buffer (z contiguous, e.g. the zero-padded FFT input of the opening
+    conv): the planar result is written straight into it (sp3d_unproject_fwd_strided)."""
     lib = load()
     dev = cam.device
     _require_cuda(cam, "cam")
     X, Y, Z = (int(c) for c in cube_size)
     V = len(views)
+    if out is not None:
+        assert layout == LAYOUT_NHWC and not channels_last and not want_grids and pass_mask is None and variant is None
+        assert tuple(out.shape) == (B, J, X, Y, Z) and out.stride(4) == 1 and out.dtype == out_dtype
+        flags = (HM_BF16 if views[0].dtype == torch.bfloat16 else 0) | (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
+        st = (C.c_int64 * 4)(*[int(v) for v in out.stride()[:4]])
+        rc = lib.sp3d_unproject_fwd_strided(_ptr_array(views), layout | flags, jp, cam.data_ptr(),
+                                            sample_of.data_ptr() if sample_of is not None else None, centers.data_ptr(),
+                                            valid.data_ptr(), out.data_ptr(), st, B, V, J, h, w, X, Y, Z, _f3(grid_size),
+                                            int(img_size[0]), int(img_size[1]), _stream(dev))
+        check(rc, "sp3d_unproject_fwd_strided")
+        return out, None
     if channels_last:
         cubes = torch.empty((B, X, Y, Z, J), dtype=out_dtype, device=dev).permute(0, 4, 1, 2, 3)
     else:
@@ -290,13 +305,33 @@ def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual
 
 def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mask: torch.Tensor, batch: int,
                          num_views: int, J: int, jp: int, h: int, w: int, cube_size, grid_size, img_size,
-                         sample_of: Optional[torch.Tensor] = None):
-    """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer"""
+                         sample_of: Optional[torch.Tensor] = None, deterministic: bool = False):
+    """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer.
+    ``deterministic``: accumulate in 64-bit fixed point (integer atomics): bit-identical run to run."""
     lib = load()
     dev = cam.device
     P = int(grad_cubes.shape[0])
     X, Y, Z = (int(c) for c in cube_size)
     gc = grad_cubes[:, :J].float().contiguous()
+    if deterministic:
+        I, Pp, V_ = C.c_int, C.c_void_p, C.c_void_p
+        lib.sp3d_unproject_bwd_packed_det.restype = I
+        lib.sp3d_unproject_bwd_packed_det.argtypes = [Pp] * 8 + [I] * 10 + [Pp, I, I, V_]
+        lib.sp3d_fixed_to_float.restype = I
+        lib.sp3d_fixed_to_float.argtypes = [Pp, Pp, Pp, C.c_int64, V_]
+        # scale = 2^(40 - ceil(log2 max|g|)): computed on the device, no host synchronisation
+        gmax = gc.abs().amax().clamp_min(1e-30)
+        scale = torch.exp2(40.0 - torch.ceil(torch.log2(gmax))).to(torch.float32).reshape(1)
+        fixed = torch.zeros((num_views, batch, h, w, jp), dtype=torch.int64, device=dev)
+        rc = lib.sp3d_unproject_bwd_packed_det(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
+                                               centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),
+                                               fixed.data_ptr(), scale.data_ptr(), int(batch), P, num_views, J, jp, h, w,
+                                               X, Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
+        check(rc, "sp3d_unproject_bwd_packed_det")
+        packed = torch.empty((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
+        check(lib.sp3d_fixed_to_float(fixed.data_ptr(), packed.data_ptr(), scale.data_ptr(), fixed.numel(), _stream(dev)),
+              "sp3d_fixed_to_float")
+        return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
     packed = torch.zeros((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
     rc = lib.sp3d_unproject_bwd_packed(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                        centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),

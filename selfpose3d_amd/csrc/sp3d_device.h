@@ -33,6 +33,13 @@ struct Geom {
     const int *sample_of;         // optional (P): heat-map / camera row each output cube reads (NULL: identity)
     int xcd_chunk;                // tiles per chunk of the XCD-affine tile map (power of two)
     int xcd_order;                // 0: chunks in sweep order, 1: centre of the volume first
+    // planar result addressing (pipelined / brick kernels): element (p, j, x, y, z) lives at p*sB + j*sJ + x*sX + y*sY + z.
+    // Dense (B,J,X,Y,Z): sB = J*N, sJ = N, sX = Y*Z, sY = Z.  Other strides let the kernel write straight into a larger
+    // buffer (the zero-padded input of the frequency-domain opening conv, sp3d_unproject_fwd_strided).
+    long long sB;
+    int sJ, sX, sY;
+    int dense;                    // 1: the strides are the dense ones (flat voxel index == offset)
+    int vec4;                     // 1: rows are 4-element aligned, 16-byte result pieces are allowed
     uint16_t *pass_mask;          // optional (P,N): bit j set iff 0 <= pre-clamp value of channel j <= 1 and the
                                   // voxel is not NaN-zeroed (where torch's clamp / index_put_ let gradient through)
 };

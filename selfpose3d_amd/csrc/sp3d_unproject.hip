@@ -18,6 +18,8 @@
 //                            through LDS as coalesced dwordx4 rows.
 //   unproject_bwd_kernel     recomputes the forward value (clamp mask) and scatters
 //                            g * w_tap with hardware fp32 atomics.
+#include <type_traits>
+
 #include "sp3d_device.h"
 
 namespace sp3d {
@@ -517,12 +519,21 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
     const int n0 = tile * (64 * NW) + wave * 64;                          // first voxel of this wave
     if (n0 >= g.N) return;
     const int nvox = min(64, g.N - n0);
-    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
+    TO *cb = reinterpret_cast<TO *>(cubes) + (OUTCL ? (size_t)b * g.J * g.N : (size_t)b * g.sB);
     float *ws = smem + wave * WLDS;
+    // offset of voxel n inside one channel plane of a planar result (== n for the dense layout)
+    auto plane_off = [&](int n) -> size_t {
+        if (g.dense) return (size_t)n;
+        int vx, rem, vy, vz;
+        udiv_magic((uint32_t)n, (uint32_t)g.YZ, g.magicYZ, vx, rem);
+        udiv_magic((uint32_t)rem, (uint32_t)g.Z, g.magicZ, vy, vz);
+        return (size_t)vx * g.sX + (size_t)vy * g.sY + vz;
+    };
 
     if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        const size_t zo = OUTCL ? 0 : plane_off(n0 + (lane < nvox ? lane : 0));
         for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) Store4<TO>::store1(cb + (OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.N + n0 + lane)), 0.0f);
+            if (lane < nvox) Store4<TO>::store1(cb + (OUTCL ? ((size_t)(n0 + lane) * g.J + j) : ((size_t)j * g.sJ + zo)), 0.0f);
         if (grids && lane < nvox) {
             float *gp = grids + ((size_t)b * g.N + n0 + lane) * 3;
             gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
@@ -619,16 +630,19 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
     if (OUTCL) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (((g.N & 3) == 0) && nvox == 64) {
+    // 4 consecutive voxels form one 16-byte piece when they lie in one z-column (dense: any 4; strided: Z % 4 == 0)
+    if (g.vec4 && ((g.N & 3) == 0) && nvox == 64 && (g.dense || (g.Z & 3) == 0)) {
         // lane -> (channel j = pass*4 + lane/16, voxel quad u = lane%16): 256 B contiguous per channel
+        const int u = lane & 15;
+        const size_t po = plane_off(n0 + 4 * u);
         for (int j = lane >> 4; j < g.J; j += 4) {
-            const int u = lane & 15;
             const float4 o = *reinterpret_cast<const float4 *>(&ws[j * WOSTR + 4 * u]);
-            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)j * g.N + n0 + 4 * u, o);
+            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(cb + (size_t)j * g.sJ + po, o);
         }
     } else {
+        const size_t po = plane_off(n0 + (lane < nvox ? lane : 0));
         for (int j = 0; j < g.J; ++j)
-            if (lane < nvox) Store4<TO>::store1(cb + (size_t)j * g.N + n0 + lane, ws[j * WOSTR + lane]);
+            if (lane < nvox) Store4<TO>::store1(cb + (size_t)j * g.sJ + po, ws[j * WOSTR + lane]);
     }
 }
 
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
     const int bs = g.sample_of ? g.sample_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = bx * BR, y0 = by * BR, zbase = zc * zw * BR, z0 = zbase + wave * BR;
-    TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
+    TO *cb = reinterpret_cast<TO *>(cubes) + (OUTCL ? (size_t)b * g.J * g.N : (size_t)b * g.sB);
     float *ws = bsmem + wave * WLDS;
 
     // P1 mapping: this lane's voxel
@@ -709,8 +723,9 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
 
     if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
         if (inb) {
+            const size_t zo = (size_t)vx * g.sX + (size_t)vy * g.sY + vz;
             for (int j = 0; j < g.J; ++j)
-                Store4<TO>::store1(cb + (OUTCL ? ((size_t)n * g.J + j) : ((size_t)j * g.N + n)), 0.0f);
+                Store4<TO>::store1(cb + (OUTCL ? ((size_t)n * g.J + j) : ((size_t)j * g.sJ + zo)), 0.0f);
             if (grids) {
                 float *gp = grids + ((size_t)b * g.N + n) * 3;
                 gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
@@ -781,16 +796,16 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
     const int sx = x0 + (col >> 2), sy = y0 + (col & 3), sz = zbase + wz * BR;
     if (sx >= g.X || sy >= g.Y || sz >= g.Z) return;
     const float *tile = bsmem + wz * WLDS + col * 4;
-    TO *dst = cb + ((size_t)sx * g.Y + sy) * g.Z + sz;
-    if ((g.Z & 3) == 0) {
+    TO *dst = cb + (size_t)sx * g.sX + (size_t)sy * g.sY + sz;
+    if (g.vec4 && (g.Z & 3) == 0) {
         for (int j = jj; j < g.J; j += 4) {
             const float4 o = *reinterpret_cast<const float4 *>(tile + j * WOSTR);
-            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(dst + (size_t)j * g.N, o);
+            if (!SP3D_DIAG_ON(1) || o.x == 123456.0f) Store4<TO>::store_nt(dst + (size_t)j * g.sJ, o);
         }
     } else {
         const int nz = min(BR, g.Z - sz);
         for (int j = jj; j < g.J; j += 4)
-            for (int k = 0; k < nz; ++k) Store4<TO>::store1(dst + (size_t)j * g.N + k, tile[j * WOSTR + k]);
+            for (int k = 0; k < nz; ++k) Store4<TO>::store1(dst + (size_t)j * g.sJ + k, tile[j * WOSTR + k]);
     }
 }
 
@@ -898,15 +913,26 @@ __global__ __launch_bounds__(TILE) void unproject_bwd_kernel(Views hm, const flo
 //   load grad tile (J rows of 64 voxels, coalesced) -> LDS, pass mask / view masks per voxel -> LDS
 //   S    lane = (v4, ch): for its 16 voxels, g = pass ? grad / den : 0, then per bound view 4 atomics
 // ------------------------------------------------------------------------------------------
-template <int JP, bool XCD>
+// DET: accumulate in 64-bit FIXED POINT (value * *scale, rounded to nearest) with integer atomics.  Integer addition is
+// associative, so the result does not depend on the order in which the hardware retires the atomics: bit-identical
+// run to run (what SURVEY.md §5 asks for, since the reference's grid_sampler_2d_backward is order-dependent too);
+// sp3d_fixed_to_float converts back.  *scale = 2^k chosen by the caller from max|grad| so that 2^40 steps span it.
+template <int JP, bool XCD, bool DET = false>
 __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restrict__ cam,
                                                            const float *__restrict__ centers,
                                                            const uint8_t *__restrict__ valid,
                                                            const float *__restrict__ grad_cubes,
                                                            const uint16_t *__restrict__ pass_mask,
-                                                           float *__restrict__ grad_packed, size_t view_stride,
-                                                           Geom g, int tiles_per_sample)
+                                                           void *__restrict__ grad_packed_, size_t view_stride,
+                                                           Geom g, int tiles_per_sample, const float *__restrict__ scale_p)
 {
+    using ACC = typename std::conditional<DET, unsigned long long, float>::type;
+    ACC *grad_packed = reinterpret_cast<ACC *>(grad_packed_);
+    const double scale = DET ? (double)*scale_p : 1.0;
+    auto add = [&](ACC *p, float val) {
+        if constexpr (DET) atomicAdd(p, (unsigned long long)__double2ll_rn((double)val * scale));
+        else unsafeAtomicAdd(p, val);
+    };
     extern __shared__ __attribute__((aligned(16))) float bsm[];
     float *rec = bsm;                                  // [V][5][64]
     int *reci = reinterpret_cast<int *>(rec);
@@ -965,7 +991,7 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
     const int v4 = lane >> 4, ch = lane & 15;
     if (ch >= JP) return;
     const size_t rowf = (size_t)g.w * JP;
-    float *gbase = grad_packed + (size_t)bs * g.h * rowf + ch;
+    ACC *gbase = grad_packed + (size_t)bs * g.h * rowf + ch;
 #pragma unroll 1
     for (int m = 0; m < 16; ++m) {
         const int v = 4 * m + v4;
@@ -975,14 +1001,21 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
             const int c = __ffs((int)views) - 1;
             views &= views - 1;
             const int rb = c * 320 + v;
-            float *p = gbase + (size_t)c * view_stride + reci[rb];
+            ACC *p = gbase + (size_t)c * view_stride + reci[rb];
             const float w00 = rec[rb + 64], w10 = rec[rb + 128], w01 = rec[rb + 192], w11 = rec[rb + 256];
-            if (w00 != 0.0f) unsafeAtomicAdd(p, gv * w00);
-            if (w10 != 0.0f) unsafeAtomicAdd(p + JP, gv * w10);
-            if (w01 != 0.0f) unsafeAtomicAdd(p + rowf, gv * w01);
-            if (w11 != 0.0f) unsafeAtomicAdd(p + rowf + JP, gv * w11);
+            if (w00 != 0.0f) add(p, gv * w00);
+            if (w10 != 0.0f) add(p + JP, gv * w10);
+            if (w01 != 0.0f) add(p + rowf, gv * w01);
+            if (w11 != 0.0f) add(p + rowf + JP, gv * w11);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long *__restrict__ acc, float *__restrict__ out,
+                                                            const float *__restrict__ scale_p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)((double)acc[i] / (double)*scale_p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1005,6 +1038,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.xcd_chunk = 1;
     g.xcd_order = 0;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
+    g.sB = (long long)J * N; g.sJ = (int)N; g.sX = Y * Z; g.sY = Z; g.dense = 1; g.vec4 = 1;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
     g.rW_in = 1.0f / (float)W_in; g.rH_in = 1.0f / (float)H_in;
     g.rw1 = w > 1 ? 1.0f / (float)(w - 1) : 0.0f; g.rh1 = h > 1 ? 1.0f / (float)(h - 1) : 0.0f;
@@ -1282,6 +1316,34 @@ extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_l
     return SP3D_EINVAL;
 }
 
+extern "C" int sp3d_unproject_fwd_strided(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
+                                          const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                                          float *cubes, const int64_t *out_strides, int P, int V, int J, int h, int w,
+                                          int X, int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !cubes || !out_strides) return SP3D_ENULL;
+    const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
+    const int io = ((hm_layout & SP3D_HM_BF16) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0);
+    if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || out_cl || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
+    const int64_t sB = out_strides[0], sJ = out_strides[1], sX = out_strides[2], sY = out_strides[3];
+    // the planes must not overlap and must fit 32-bit in-plane offsets
+    if (sY < Z || sX < (int64_t)Y * sY || sJ < (int64_t)X * sX || sB < (int64_t)J * sJ) return SP3D_EINVAL;
+    if (sJ > 0x7fffffff) return SP3D_ERANGE;
+    g.sB = sB; g.sJ = (int)sJ; g.sX = (int)sX; g.sY = (int)sY;
+    g.dense = (sY == Z && sX == (int64_t)Y * Z && sJ == (int64_t)g.N && sB == (int64_t)J * g.N) ? 1 : 0;
+    // 16-byte pieces need 4-element aligned rows (and a 16-byte aligned base pointer); otherwise the kernels take their
+    // scalar store path, which is correct for any stride but slow
+    g.sample_of = sample_of;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    g.vec4 = ((g.dense || ((sY | sX | sJ | sB) & 3) == 0) && ((uintptr_t)cubes & 15) == 0) ? 1 : 0;
+    return launch_nhwc(v, Jp, cam, centers, valid, cubes, nullptr, g, default_variant(g, false), false, io, (hipStream_t)stream);
+}
+
 extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam,
                                   const float *centers, const uint8_t *valid, float *cubes, float *grids, int B,
                                   int V, int J, int h, int w, int X, int Y, int Z, const float *grid_size, int W_in,
@@ -1371,16 +1433,16 @@ extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_lay
                        (hipStream_t)stream);
 }
 
-extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers,
-                                         const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
-                                         float *grad_packed, int B, int P, int V, int J, int Jp, int h, int w, int X,
-                                         int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream)
+static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
+                           const float *grad_cubes, const uint16_t *pass_mask, void *grad_acc, const float *scale, int B,
+                           int P, int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
+                           int W_in, int H_in, void *stream)
 {
     Geom g;
     int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
     if (rc) return rc;
     if (B <= 0) return SP3D_EINVAL;
-    if (!cam || !centers || !valid || !grad_cubes || !pass_mask || !grad_packed) return SP3D_ENULL;
+    if (!cam || !centers || !valid || !grad_cubes || !pass_mask || !grad_acc) return SP3D_ENULL;
     if (Jp < J || (Jp & 3) || Jp > 16 || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
     g.sample_of = sample_of;
     const int tiles = (g.N + 63) / 64;
@@ -1388,12 +1450,43 @@ extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample
     const size_t lds = (size_t)(V * 320 + Jp * 64 + 64) * sizeof(float);
     dim3 grid(xcd_grid_blocks(P, tiles, g.xcd_chunk)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    switch (Jp) {
-    case 4: hipLaunchKernelGGL((unproject_bwd2_kernel<4, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
-    case 8: hipLaunchKernelGGL((unproject_bwd2_kernel<8, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
-    case 12: hipLaunchKernelGGL((unproject_bwd2_kernel<12, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
-    default: hipLaunchKernelGGL((unproject_bwd2_kernel<16, true>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_packed, view_stride, g, tiles); break;
+#define SP3D_B2(JP_, DET_) hipLaunchKernelGGL((unproject_bwd2_kernel<JP_, true, DET_>), grid, block, lds, s, cam, centers, valid, grad_cubes, pass_mask, grad_acc, view_stride, g, tiles, scale)
+    if (scale) {
+        switch (Jp) { case 4: SP3D_B2(4, true); break; case 8: SP3D_B2(8, true); break; case 12: SP3D_B2(12, true); break; default: SP3D_B2(16, true); break; }
+    } else {
+        switch (Jp) { case 4: SP3D_B2(4, false); break; case 8: SP3D_B2(8, false); break; case 12: SP3D_B2(12, false); break; default: SP3D_B2(16, false); break; }
     }
+#undef SP3D_B2
+    return launch_status();
+}
+
+extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers,
+                                         const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
+                                         float *grad_packed, int B, int P, int V, int J, int Jp, int h, int w, int X,
+                                         int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream)
+{
+    return bwd_packed_impl(cam, sample_of, centers, valid, grad_cubes, pass_mask, grad_packed, nullptr, B, P, V, J, Jp, h, w,
+                           X, Y, Z, grid_size, W_in, H_in, stream);
+}
+
+extern "C" int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sample_of, const float *centers,
+                                             const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
+                                             int64_t *grad_fixed, const float *scale, int B, int P, int V, int J, int Jp,
+                                             int h, int w, int X, int Y, int Z, const float *grid_size, int W_in, int H_in,
+                                             void *stream)
+{
+    if (!scale) return SP3D_ENULL;
+    return bwd_packed_impl(cam, sample_of, centers, valid, grad_cubes, pass_mask, grad_fixed, scale, B, P, V, J, Jp, h, w, X,
+                           Y, Z, grid_size, W_in, H_in, stream);
+}
+
+extern "C" int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream)
+{
+    if (n <= 0) return SP3D_EINVAL;
+    if (!acc || !out || !scale) return SP3D_ENULL;
+    if ((n + 255) / 256 > 0x7fffffff) return SP3D_ERANGE;
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long *>(acc), out, scale, (size_t)n);
     return launch_status();
 }
 

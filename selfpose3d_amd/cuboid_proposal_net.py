@@ -74,8 +74,11 @@ class CuboidProposalNet(nn.Module):
         else:
             hms = all_heatmaps
         planar = self.v2v_net.wants_planar_input() and hms[0].is_cuda      # FFT opening conv: plain J-channel cubes
+        # ... which the unprojection kernel writes straight into that conv's zero-padded input buffer
+        out = self.v2v_net.input_view(hms[0].shape[0], *self.cube_size, hms[0].device) \
+            if planar and hms[0].shape[1] <= 16 and not torch.is_grad_enabled() else None
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
                                                 flip_xcoords=flip_xcoords, want_grids=False, pad_channels=not planar,
-                                                channels_last=self.channels_last and not planar)
+                                                channels_last=self.channels_last and not planar, out=out)
         root_cubes = self.v2v_net(cubes).squeeze(1)
         return root_cubes, self.proposal_layer(root_cubes, meta)

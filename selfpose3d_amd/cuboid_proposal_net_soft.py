@@ -66,9 +66,11 @@ class CuboidProposalNetSoft(nn.Module):
     # -- shared: heat-maps -> root cubes ---------------------------------------------------------------
     def _root_cubes(self, hms, meta, flip_xcoords):
         planar = self.v2v_net.wants_planar_input() and hms[0].is_cuda      # FFT opening conv: plain J-channel cubes
+        out = self.v2v_net.input_view(hms[0].shape[0], *self.cube_size, hms[0].device) \
+            if planar and hms[0].shape[1] <= 16 and not torch.is_grad_enabled() else None
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
                                                 flip_xcoords=flip_xcoords, want_grids=False, pad_channels=not planar,
-                                                channels_last=self.channels_last and not planar)
+                                                channels_last=self.channels_last and not planar, out=out)
         return self.v2v_net(cubes).squeeze(1)
 
     def get_grid_centres(self, all_heatmaps, meta, flip_xcoords=None):

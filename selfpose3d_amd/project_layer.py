@@ -13,6 +13,7 @@ tensors must live on the GPU and libsp3d.so must be built, otherwise this raises
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Sequence
 
 import numpy as np
@@ -86,7 +87,7 @@ class _UnprojectFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, cam, centers, valid, grid_size, cube_size, want_grids, mode, pad_channels, channels_last,
-                sample_of, *heatmaps):
+                sample_of, out, *heatmaps):
         _, J, h, w = heatmaps[0].shape
         B = int(centers.shape[0])                 # number of output cubes (== batch unless `sample_of` is given)
         hms = [x.detach() for x in heatmaps]
@@ -105,7 +106,7 @@ class _UnprojectFn(torch.autograd.Function):
             views = [packed[c] for c in range(len(hms))]
             # when a gradient will be asked for, let the kernel also emit the clamp pass mask: the backward
             # then runs the line-coalesced scatter without re-reading any heat-map
-            need_grad = io == torch.float32 and any(ctx.needs_input_grad[11:]) and w >= 2 and h >= 2
+            need_grad = io == torch.float32 and any(ctx.needs_input_grad[12:]) and w >= 2 and h >= 2
             X, Y, Z = cube_size
             mask = torch.empty((B, X * Y * Z), dtype=torch.int16, device=cam.device) if need_grad else None
             # pad_channels: run the kernel over all jp channels - the padded ones are zero in `packed`,
@@ -113,7 +114,7 @@ class _UnprojectFn(torch.autograd.Function):
             cubes, grids = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, B,
                                               jp if pad_channels else J, h, w, cube_size, grid_size, layer.img_size,
                                               want_grids, channels_last=channels_last, sample_of=sample_of,
-                                              out_dtype=io, pass_mask=mask)
+                                              out_dtype=io, pass_mask=mask, out=None if need_grad else out)
             ctx.packed_bwd = (mask, jp, int(heatmaps[0].shape[0]), len(hms), J, h, w) if need_grad else None
         else:
             ctx.packed_bwd = None
@@ -138,11 +139,12 @@ class _UnprojectFn(torch.autograd.Function):
         if ctx.packed_bwd is not None:
             mask, jp, batch, nv, J, h, w = ctx.packed_bwd
             grads = _lib.unproject_bwd_packed(cam, centers, valid, grad_cubes, mask, batch, nv, J, jp, h, w, cube_size,
-                                              grid_size, ctx.layer.img_size, sample_of=ctx.sample_of)
-            return (None,) * 11 + tuple(grads)
+                                              grid_size, ctx.layer.img_size, sample_of=ctx.sample_of,
+                                              deterministic=ctx.layer.deterministic_backward)
+            return (None,) * 12 + tuple(grads)
         grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size,
                                    sample_of=ctx.sample_of)
-        return (None,) * 11 + tuple(grads)
+        return (None,) * 12 + tuple(grads)
 
 
 class ProjectLayer(nn.Module):
@@ -161,6 +163,8 @@ class ProjectLayer(nn.Module):
         self._cam_key = None
         self._cam_dev = None
         self._static_cam = None       # see static_camera_table()
+        # gradient scatter in 64-bit fixed point (bit-identical run to run) instead of fp32 atomics; SP3D_BWD_DETERMINISTIC=1
+        self.deterministic_backward = os.environ.get("SP3D_BWD_DETERMINISTIC", "0") not in ("", "0")
 
     @contextlib.contextmanager
     def static_camera_table(self, table: torch.Tensor):
@@ -248,13 +252,14 @@ class ProjectLayer(nn.Module):
 
     # -- reference API -------------------------------------------------------------------
     def get_voxel(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None, want_grids=True,
-                  pad_channels=False, channels_last=False, sample_of=None):
+                  pad_channels=False, channels_last=False, sample_of=None, out=None):
         """Reference semantics (project_layer.py:42-102).  Extras for in-repo callers only:
         ``want_grids=False`` skips the (B,N,3) grid output, ``pad_channels`` returns
         ceil4(J) channels (zeros beyond J) and ``channels_last`` returns torch.channels_last_3d
         strides - both let MIOpen's 3D convolutions run their fast paths without a copy;
         ``sample_of`` (int (P,)) with ``grid_center`` (P,5|3): P cubes, cube p read from sample
-        sample_of[p] (all person proposals of a batch in one launch)."""
+        sample_of[p] (all person proposals of a batch in one launch); ``out``: a (P,J,X,Y,Z) view of a larger buffer
+        (z contiguous) that receives the planar result directly - no grids, inference only."""
         device = heatmaps[0].device
         if not heatmaps[0].is_cuda:
             raise _lib.Sp3dError("ProjectLayer: heat-maps must be on the GPU (no CPU fallback)")
@@ -281,9 +286,11 @@ class ProjectLayer(nn.Module):
             pad_channels = channels_last = False
         if channels_last and not pad_channels and (J & 3):
             channels_last = False
+        if out is not None and (mode != "nhwc" or want_grids or pad_channels or channels_last):
+            raise _lib.Sp3dError("get_voxel(out=...): planar NHWC-path result without grids only")
         cubes, grids = _UnprojectFn.apply(self, cam, centers, valid, [float(v) for v in grid_size],
                                           [int(v) for v in cube_size], bool(want_grids), mode, bool(pad_channels),
-                                          bool(channels_last), sample_of, *heatmaps)
+                                          bool(channels_last), sample_of, out, *heatmaps)
         return cubes, (grids if want_grids else None)
 
     def forward(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None):

@@ -288,6 +288,35 @@ class _FoldedV2V:
 
     _fft_len = staticmethod(fft_len)
 
+    @classmethod
+    def _fft_shape(cls, X, Y, Z, k):
+        """padded transform lengths: >= n + k//2 zeros behind the signal, rocFFT-friendly factors, and a z length that
+        is a multiple of 4 so that every row of the buffer starts 16-byte aligned"""
+        sz = cls._fft_len(Z + k - 1)
+        while sz % 4:
+            sz = cls._fft_len(sz + 2)
+        return (cls._fft_len(X + k - 1), cls._fft_len(Y + k - 1), sz)
+
+    def _fft_buffer(self, B, cin, S, device):
+        bkey = ("xpad", B, cin, S, str(device))
+        buf = self.t.get(bkey)
+        if buf is None:
+            buf = self.t[bkey] = torch.zeros((B, cin) + S, dtype=torch.float32, device=device)
+        return buf
+
+    def fft_input_view(self, B, X, Y, Z, device):
+        """(B,cin,X,Y,Z) view of the zero-padded input buffer of the frequency-domain opening conv: a producer
+        (ProjectLayer.get_voxel(out=...)) that fills it saves the pad/copy pass; `run` recognises the view."""
+        key = self._key(self.net)
+        if key != self.key:
+            self._build()
+            self.key = key
+        w0 = self.t["front"][0]
+        cin, k = int(w0.shape[1]), int(w0.shape[2])
+        if not (self.net.fft_front and k == 7):
+            return None
+        return self._fft_buffer(B, cin, self._fft_shape(X, Y, Z, k), device)[:, :, :X, :Y, :Z]
+
     def _front_fft(self, x, w0, s0):
         """the 7x7x7 opening conv in the frequency domain: zero-padded rFFT (rocFFT via torch.fft) ->
         sp3d_freq_contract -> irFFT -> crop + shift + ReLU.  3.3x (80x80x20, B=4) to 4.7x (64^3) faster than the
@@ -295,17 +324,19 @@ class _FoldedV2V:
         from . import _lib
         B, _, X, Y, Z = x.shape
         cin, k = int(w0.shape[1]), int(w0.shape[2])
-        p = k // 2
-        S = (self._fft_len(X + k - 1), self._fft_len(Y + k - 1), self._fft_len(Z + k - 1))
+        S = self._fft_shape(X, Y, Z, k)
         wkey = ("Wf", S)
         if wkey not in self.t:
-            wf = torch.fft.rfftn(w0.contiguous().float(), s=S, dim=(2, 3, 4))
-            self.t[wkey] = torch.conj(wf).resolve_conj().contiguous()           # correlation, not convolution
-        bkey = ("xpad", B, cin, S, str(x.device))
-        buf = self.t.get(bkey)
-        if buf is None:                                                         # borders stay zero across calls
-            buf = self.t[bkey] = torch.zeros((B, cin) + S, dtype=torch.float32, device=x.device)
-        buf[:, :, p:p + X, p:p + Y, p:p + Z].copy_(x[:, :cin])
+            # the signal sits at the ORIGIN of the padded buffer (so a producer can write 16-byte aligned rows into it,
+            # fft_input_view), hence the kernel is centred on the origin: taps -p..p wrap around to S-p..S-1
+            wp = torch.zeros(tuple(w0.shape[:2]) + S, dtype=torch.float32, device=w0.device)
+            wp[:, :, :k, :k, :k] = w0.float()
+            wp = torch.roll(wp, shifts=(-(k // 2),) * 3, dims=(2, 3, 4))
+            self.t[wkey] = torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj().contiguous()   # correlation
+        buf = self._fft_buffer(B, cin, S, x.device)
+        view = buf[:, :, :X, :Y, :Z]
+        if not (x.data_ptr() == view.data_ptr() and x.shape == view.shape and x.stride() == view.stride()):
+            view.copy_(x[:, :cin])                                              # borders stay zero across calls
         Yf = _lib.freq_contract(torch.fft.rfftn(buf, dim=(2, 3, 4)), self.t[wkey])
         y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[:, :, :X, :Y, :Z]
         w1 = self.t["front_res"][0]             # a 3x3x3 weight tells the layout the conv stack runs in
@@ -392,6 +423,15 @@ class V2VNet(nn.Module):
                 self._plan = _FoldedV2V(self)
             return self._plan.run(x)
         return self.output_layer(self.encoder_decoder(self.front_layers(x)))
+
+    def input_view(self, B, X, Y, Z, device):
+        """where the next inference forward wants its (B,Cin,X,Y,Z) input written (a view of the FFT opening conv's
+        padded buffer), or None when any tensor will do"""
+        if not (self.wants_planar_input() and torch.device(device).type == "cuda" and X % 4 == 0 and Y % 4 == 0 and Z % 4 == 0):
+            return None
+        if self._plan is None:
+            self._plan = _FoldedV2V(self)
+        return self._plan.fft_input_view(B, X, Y, Z, device)
 
     def wants_planar_input(self) -> bool:
         """True when the next forward will take the FFT opening conv: it reads plain (B,C,X,Y,Z) cubes with the real

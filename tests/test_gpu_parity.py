@@ -781,3 +781,56 @@ def test_backbone_emits_unprojection_ready_heatmaps(dev):
     for o, r in zip(outs, ref):
         assert o.shape == r.shape == (2, 15, 16, 24)
         assert float((o - r).abs().max()) <= 1e-4 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("name", ["unproj_coarse_full_96x72", "unproj_fine_small", "unproj_coarse_aug", "unproj_coarse_j1_v1",
+                                  "unproj_fine_full_240x128"])
+def test_strided_result_into_a_larger_buffer(dev, name):
+    """sp3d_unproject_fwd_strided: the planar result lands inside a larger buffer (the FFT conv's zero-padded input),
+    bit-identical to the dense result, nothing outside the addressed elements is touched; aligned and unaligned rows"""
+    from selfpose3d_amd import _lib
+    case = gio.Case(name)
+    base, _ = _hip_fwd(case, dev, "nhwc", want_grids=False)
+    hms = [h.to(dev) for h in case.hms]
+    cam = torch.from_numpy(case.cam).to(dev)
+    centers = torch.from_numpy(case.centers).to(dev)
+    valid = torch.from_numpy(case.valid).to(dev)
+    w, h = case.hm
+    jp = 4 if case.J <= 4 else (8 if case.J <= 8 else (12 if case.J <= 12 else 16))
+    packed = _lib.pack_heatmaps(hms, jp=jp)
+    views = [packed[c] for c in range(case.V)]
+    X, Y, Z = case.cube
+    for pad in ((6, 8, 8), (3, 5, 6), (0, 0, 0)):            # 16-byte aligned rows / unaligned rows / dense strides
+        buf = torch.full((case.B, case.J + 1, X + pad[0], Y + pad[1], Z + pad[2]), -7.0, device=dev)
+        view = buf[:, :case.J, :X, :Y, :Z]
+        got, _ = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, jp, cam, centers, valid, case.B, case.J, h, w, case.cube,
+                                    case.grid_size, case.img, False, out=view)
+        assert got.data_ptr() == view.data_ptr()
+        assert torch.equal(view, base), pad
+        mask = torch.ones_like(buf, dtype=torch.bool)
+        mask[:, :case.J, :X, :Y, :Z] = False
+        assert torch.all(buf[mask] == -7.0)
+
+
+def test_deterministic_backward_is_bit_reproducible(dev):
+    """SP3D_BWD_DETERMINISTIC: 64-bit fixed-point accumulation - the same bits on every run (the fp32-atomic scatter is
+    only reproducible up to rounding order), and within 1e-6 of the float64 gradient of the reference"""
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    for name in ("unproj_grad_small", "unproj_grad_fine_aug"):
+        case = gio.Case(name)
+        cfg = load_config(None, NETWORK__IMAGE_SIZE=case.img, NETWORK__HEATMAP_SIZE=case.hm)
+        layer = ProjectLayer(cfg)
+        layer.deterministic_backward = True
+        gc = case.grid_center if isinstance(case.grid_center, list) else case.grid_center.to(dev)
+        wgt = torch.from_numpy(np.random.default_rng(int(case.g["grad_seed"])).standard_normal(
+            (case.B, case.J, *case.cube)).astype(np.float32)).to(dev)
+        runs = []
+        for _ in range(3):
+            hms = [h.to(dev).requires_grad_(True) for h in case.hms]
+            cubes, _ = layer(hms, case.meta, case.grid_size, gc, case.cube, flip_xcoords=case.flip)
+            (cubes * wgt).sum().backward()
+            runs.append(torch.stack([h.grad for h in hms]))
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        ref = case.g["grad_hm"]
+        assert np.abs(runs[0].cpu().numpy() - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max()))

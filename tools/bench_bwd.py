@@ -38,6 +38,8 @@ for name, B, V, cube, gs, fine in (("coarse_b2", 2, 5, syn.INITIAL_CUBE_SIZE, sy
                        False, sample_of=sample_of, pass_mask=mask)
     res[name]["bwd_packed_us"] = round(timed(lambda: _lib.unproject_bwd_packed(cam, centers, valid, g, mask, B, V, J, 16, h, w,
                                                                                 cube, gs, img, sample_of=sample_of)), 1)
+    res[name]["bwd_packed_deterministic_us"] = round(timed(lambda: _lib.unproject_bwd_packed(
+        cam, centers, valid, g, mask, B, V, J, 16, h, w, cube, gs, img, sample_of=sample_of, deterministic=True)), 1)
     res[name]["fwd_train_us"] = round(timed(lambda: _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam,
                                                                         centers, valid, P, J, h, w, cube, gs, img, False,
                                                                         sample_of=sample_of, pass_mask=mask)), 1)
