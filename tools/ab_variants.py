@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--variants", type=str, default="24,56")
+    ap.add_argument("--variants", type=str, default="24,56,120")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     variants = [int(v) for v in args.variants.split(",")]
@@ -68,6 +68,11 @@ def main():
         fns = {"planar": lambda: _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube,
                                                     gs, img, False),
                "pack": lambda: _lib.pack_heatmaps(hms, jp=16, out=packed)}
+        # library defaults (selfpose3d_amd/csrc/sp3d_unproject.hip: default_variant)
+        fns["nhwc_default"] = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube,
+                                                         gs, img, False)
+        fns["nhwc_default_cl"] = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w,
+                                                            cube, gs, img, False, channels_last=True)
         for v in variants:
             fns[f"nhwc_v{v}"] = (lambda v=v: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J,
                                                                 h, w, cube, gs, img, False, variant=v))
