@@ -265,8 +265,54 @@ class _FoldedV2V:
         r = x if ws is None else self._conv1(x, ws)
         return self._conv3(h, w2, u2, s2, 2, r)
 
+    # -- library GEMM selection ---------------------------------------------------------------------------------
+    # The plan's GEMMs (batched Winograd products, transposed-conv and 1x1x1 GEMMs) are plain library calls; which
+    # rocBLAS / hipBLASLt solution the library's heuristic picks matters: the 64 x (8000 x 64 x 64) batched product of a
+    # half-resolution layer runs 85 us with the default solution and 47 us with the best one (tools/exp_blas.sh).
+    # PyTorch's TunableOp does that selection: the FIRST eager forward of each input shape runs with tuning on (a few
+    # ms per GEMM shape, never during graph capture), later forwards only look the choice up.  SP3D_TUNE_GEMM=0: off.
+    _tuned_shapes: "set[tuple]" = set()
+
+    @staticmethod
+    def _tunable():
+        import os
+        if os.environ.get("SP3D_TUNE_GEMM", "1") in ("0", ""):
+            return None
+        return getattr(torch.cuda, "tunable", None)
+
+    def _run_tuned(self, x):
+        tun = self._tunable()
+        if tun is None or not x.is_cuda:
+            return self._run(x)
+        capturing = torch.cuda.is_current_stream_capturing()
+        shape_key = (tuple(x.shape), str(x.device), bool(self.net.winograd), bool(self.net.fft_front))
+        was_on, was_tuning = tun.is_enabled(), tun.tuning_is_enabled()
+        try:
+            if not was_on:
+                tun.enable(True)
+                if hasattr(tun, "write_file_on_exit"):
+                    tun.write_file_on_exit(False)          # selections live in this process only
+                else:                                      # (this torch writes them at exit: keep the cwd clean)
+                    import os
+                    import tempfile
+                    tun.set_filename(os.path.join(tempfile.gettempdir(), f"sp3d_tunableop_{os.getpid()}.csv"))
+            first = shape_key not in _FoldedV2V._tuned_shapes and not capturing
+            tun.tuning_enable(bool(first))
+            if first:
+                tun.set_max_tuning_duration(30)
+            out = self._run(x)
+            if first:
+                _FoldedV2V._tuned_shapes.add(shape_key)
+            return out
+        finally:
+            tun.tuning_enable(was_tuning)
+            # lookups stay enabled: a later forward (or graph replay capture) must find the selections
+
     @torch.no_grad()
     def run(self, x):
+        return self._run_tuned(x)
+
+    def _run(self, x):
         from . import _lib
         key = self._key(self.net)
         if key != self.key:

@@ -57,6 +57,6 @@ def run(B, C, O, grid, k, sizes):
     return out
 
 
-res = {"root_b4_c15": run(4, 15, 16, (80, 80, 20), 7, [(88, 88, 28), (88, 88, 26), (88, 88, 30), (96, 96, 28)]),
-       "pose_p6_c15": run(6, 15, 16, (64, 64, 64), 7, [(70, 70, 70), (72, 72, 72), (72, 72, 70), (77, 77, 70)])}
+res = {"root_b4_c15": run(4, 15, 16, (80, 80, 20), 7, [(88, 88, 28), (88, 88, 26), (88, 88, 32), (90, 90, 28), (96, 96, 28), (96, 96, 32), (100, 100, 28), (104, 104, 28), (112, 112, 28), (128, 128, 32)]),
+       "pose_p6_c15": run(6, 15, 16, (64, 64, 64), 7, [(70, 70, 72), (72, 72, 72), (80, 80, 80), (75, 75, 72), (77, 77, 72), (96, 96, 96)])}
 print(json.dumps(res, indent=1))
