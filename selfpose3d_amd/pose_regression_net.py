@@ -64,6 +64,21 @@ class PoseRegressionNet(nn.Module):
         centers = grid_centers[bi, ki, :3].contiguous()
         flip = None if flip_xcoords is None else flip_xcoords
         planar = self.v2v_net.wants_planar_input()                       # FFT opening conv: plain J-channel cubes
+        direct = self.v2v_net.input_chunk_views(P, max_cubes_per_call, *self.cube_size, device) \
+            if planar and J <= 16 else None
+        if direct is not None:
+            # the kernel writes every cube straight into the zero-padded input buffer of the FFT opening conv
+            whole, chunks = direct
+            self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, centers, self.cube_size, flip_xcoords=flip,
+                                         want_grids=False, sample_of=bi, out=whole)
+            outs, s0 = [], 0
+            for n, view in chunks:
+                y = self.v2v_net(view)[:n]          # a tail chunk is rounded up to a power of two (stale cubes, ignored)
+                outs.append(_lib.soft_argmax_grid(y, centers[s0:s0 + n], self.grid_size, self.cube_size,
+                                                  self.soft_argmax_layer.beta))
+                s0 += n
+            pred[bi, ki] = torch.cat(outs, 0)
+            return pred
         cubes, _ = self.project_layer.get_voxel(all_heatmaps, meta, self.grid_size, centers, self.cube_size,
                                                 flip_xcoords=flip, want_grids=False, pad_channels=not planar,
                                                 channels_last=self.channels_last and not planar, sample_of=bi)

@@ -20,14 +20,18 @@ def _bn(c):
 
 
 def fft_len(n: int) -> int:
-    """smallest even m >= n whose prime factors are <= 13 (rocFFT radices)"""
+    """smallest even m >= n whose prime factors are <= 13 (rocFFT radices) and that has at most ONE distinct odd prime
+    factor: mixed odd radices are slow in rocFFT (72 beats 70 = 2*5*7 and 88 = 8*11 beats 90 = 2*9*5 by more than
+    their size ratio, tools/exp_fftconv.py)"""
     m = n + (n & 1)
     while True:
-        r = m
+        r, odd = m, 0
         for q in (2, 3, 5, 7, 11, 13):
+            if q > 2 and r % q == 0:
+                odd += 1
             while r % q == 0:
                 r //= q
-        if r == 1:
+        if r == 1 and odd <= 1:
             return m
         m += 2
 
@@ -361,7 +365,15 @@ class _FoldedV2V:
         cin, k = int(w0.shape[1]), int(w0.shape[2])
         if not (self.net.fft_front and k == 7):
             return None
-        return self._fft_buffer(B, cin, self._fft_shape(X, Y, Z, k), device)[:, :, :X, :Y, :Z]
+        S = self._fft_shape(X, Y, Z, k)
+        view = self._fft_buffer(B, cin, S, device)[:, :, :X, :Y, :Z]
+        view._sp3d_fft_shape = S
+        return view
+
+    @staticmethod
+    def tag_fft_view(view, S):
+        view._sp3d_fft_shape = S
+        return view
 
     def _front_fft(self, x, w0, s0):
         """the 7x7x7 opening conv in the frequency domain: zero-padded rFFT (rocFFT via torch.fft) ->
@@ -379,10 +391,13 @@ class _FoldedV2V:
             wp[:, :, :k, :k, :k] = w0.float()
             wp = torch.roll(wp, shifts=(-(k // 2),) * 3, dims=(2, 3, 4))
             self.t[wkey] = torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj().contiguous()   # correlation
-        buf = self._fft_buffer(B, cin, S, x.device)
-        view = buf[:, :, :X, :Y, :Z]
-        if not (x.data_ptr() == view.data_ptr() and x.shape == view.shape and x.stride() == view.stride()):
-            view.copy_(x[:, :cin])                                              # borders stay zero across calls
+        if getattr(x, "_sp3d_fft_shape", None) == S and x.shape[1] == cin and \
+                x.stride() == (x.stride(0), S[0] * S[1] * S[2], S[1] * S[2], S[2], 1):
+            # x IS the signal corner of a zero-padded buffer (fft_input_view / fft_input_views): no pad/copy pass
+            buf = x.as_strided((B, cin) + S, x.stride(), x.storage_offset())
+        else:
+            buf = self._fft_buffer(B, cin, S, x.device)
+            buf[:, :, :X, :Y, :Z].copy_(x[:, :cin])                             # borders stay zero across calls
         Yf = _lib.freq_contract(torch.fft.rfftn(buf, dim=(2, 3, 4)), self.t[wkey])
         y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[:, :, :X, :Y, :Z]
         w1 = self.t["front_res"][0]             # a 3x3x3 weight tells the layout the conv stack runs in
@@ -478,6 +493,27 @@ class V2VNet(nn.Module):
         if self._plan is None:
             self._plan = _FoldedV2V(self)
         return self._plan.fft_input_view(B, X, Y, Z, device)
+
+    def input_chunk_views(self, P, chunk, X, Y, Z, device):
+        """for a caller that produces P inputs at once and feeds them in chunks of `chunk` (tail rounded up to a power
+        of two): ONE zero-padded buffer for all of them -> (view of the first P inputs to write into, list of per-chunk
+        views to pass to forward()).  None when the next forward does not take the FFT opening conv."""
+        first = self.input_view(1, X, Y, Z, device)
+        if first is None:
+            return None
+        S = first._sp3d_fft_shape
+        cin = first.shape[1]
+        sizes = []
+        s0 = 0
+        while s0 < P:
+            n = min(chunk, P - s0)
+            sizes.append((s0, n, 1 << (n - 1).bit_length()))
+            s0 += n
+        total = sizes[-1][0] + sizes[-1][2]
+        buf = self._plan._fft_buffer(total, cin, S, device)
+        whole = buf[:P, :, :X, :Y, :Z]
+        chunks = [(n, _FoldedV2V.tag_fft_view(buf[a:a + m, :, :X, :Y, :Z], S)) for a, n, m in sizes]
+        return whole, chunks
 
     def wants_planar_input(self) -> bool:
         """True when the next forward will take the FFT opening conv: it reads plain (B,C,X,Y,Z) cubes with the real

@@ -227,16 +227,20 @@ def test_torch_op_registry_face():
 
 
 def test_fft_lengths_for_the_opening_conv():
-    """FFT sizes of the frequency-domain 7x7x7 conv: even, >= n + 6, prime factors <= 13"""
+    """FFT sizes of the frequency-domain 7x7x7 conv: even, >= n + 6, prime factors <= 13, at most one distinct odd
+    prime (70 = 2*5*7 and 140 lose to 72 and 144 in rocFFT); the z length is a multiple of 4 (16-byte aligned rows)"""
     from selfpose3d_amd.v2v_net import _FoldedV2V
-    for n, want in ((86, 88), (26, 26), (70, 70), (22, 22), (14, 14), (46, 48), (134, 140)):
+    for n, want in ((86, 88), (26, 26), (70, 72), (22, 22), (14, 14), (46, 48), (134, 144)):
         m = _FoldedV2V._fft_len(n)
         assert m == want and m % 2 == 0 and m >= n
-        r = m
+        r, odd = m, 0
         for q in (2, 3, 5, 7, 11, 13):
+            odd += 1 if (q > 2 and r % q == 0) else 0
             while r % q == 0:
                 r //= q
-        assert r == 1
+        assert r == 1 and odd <= 1
+    assert _FoldedV2V._fft_shape(80, 80, 20, 7) == (88, 88, 28)
+    assert _FoldedV2V._fft_shape(64, 64, 64, 7) == (72, 72, 72)
 
 
 def test_project_joints_matches_reference_project_pose_batch():
