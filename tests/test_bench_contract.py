@@ -1,0 +1,62 @@
+"""bench.py pieces that can be checked without a GPU: the reference-golden output check really discriminates, the static
+reference-CPU record is well formed, and the argument defaults follow the driver's contract."""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_output_check_accepts_the_reference_and_rejects_a_perturbed_output():
+    from selfpose3d_amd import synthetic as syn
+    bench = _bench()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rootnet_full.npz"))
+    N = int(np.prod(syn.INITIAL_CUBE_SIZE))
+    # rebuild a full volume that agrees with the golden on its sub-sample and on its checksums
+    root = np.zeros((2, N), np.float32)
+    root[:, g["sub_idx"]] = g["root_sub"]
+    rest = np.setdiff1d(np.arange(N), g["sub_idx"])
+    for b in range(2):
+        root[b, rest] = (g["root_sum"][b] - root[b].astype(np.float64).sum()) / len(rest)
+    cs = torch.tensor(syn.INITIAL_CUBE_SIZE, dtype=torch.float32)
+    gs, cen = torch.tensor(syn.SPACE_SIZE), torch.tensor(syn.SPACE_CENTER)
+    gc = torch.zeros(2, 10, 5)
+    gc[:, :, :3] = torch.from_numpy(g["nms_idx"]).float() / (cs - 1) * gs + cen - gs / 2.0
+    gc[:, :, 4] = torch.from_numpy(g["nms_vals"])
+    out = (torch.from_numpy(root).view(2, *syn.INITIAL_CUBE_SIZE), gc)
+    ok = bench.check_output(out, g)
+    assert ok["ok"] and ok["proposal_indices_checked"] >= 10 and ok["proposal_indices_wrong"] == 0
+    bad = (out[0].clone(), gc.clone())
+    bad[0].view(2, -1)[0, int(g["sub_idx"][5])] += 0.01                 # one voxel off by 1e-2
+    assert not bench.check_output(bad, g)["ok"]
+    bad = (out[0], gc.clone())
+    bad[1][1, 0, 0] += 101.2658                                          # best proposal one voxel to the side
+    r = bench.check_output(bad, g)
+    assert not r["ok"] and r["proposal_indices_wrong"] == 1
+
+
+def test_cpu_reference_record_and_defaults():
+    bench = _bench()
+    rec = bench.cpu_reference_record()
+    assert rec is not None and rec["kind"] == "reference" and rec["unit"] == "samples/s"
+    assert rec["value"] > rec["value_1_thread"] > 0 and rec["cores"] == rec["host"]["logical_cpus"]
+    raw = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference.json")))
+    assert "configs[1] B=4 960x512->240x128" in raw["configs"]
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (a.gpus, a.batch) == (1, 4) and a.steps >= 20 and a.warmup >= 1 and not a.planar_input
+    assert bench.HBM_PEAK_GBS == 8000.0
