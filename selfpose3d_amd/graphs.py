@@ -42,6 +42,7 @@ class GraphedRootNet:
         # the captured kernels read the folded inference plan's tensors by address: keep them alive even if the net
         # drops its plan later (train() / load_state_dict / invalidate_plan)
         self._plan = getattr(getattr(net, "v2v_net", None), "_plan", None)
+        self._plan_tensors = dict(self._plan.t) if self._plan is not None else None     # incl. the padded FFT buffers
 
     def __call__(self, meta=None):
         """one step: pack the (possibly new) camera table, upload it asynchronously, replay"""

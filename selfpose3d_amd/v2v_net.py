@@ -348,11 +348,13 @@ class _FoldedV2V:
         return (cls._fft_len(X + k - 1), cls._fft_len(Y + k - 1), sz)
 
     def _fft_buffer(self, B, cin, S, device):
-        bkey = ("xpad", B, cin, S, str(device))
+        """zero-padded input buffer for B volumes: ONE buffer per (cin, S, device), grown when a larger batch shows
+        up and sliced otherwise (the padding is never written, so any prefix of it is a valid padded buffer)"""
+        bkey = ("xpad", cin, S, str(device))
         buf = self.t.get(bkey)
-        if buf is None:
+        if buf is None or buf.shape[0] < B:
             buf = self.t[bkey] = torch.zeros((B, cin) + S, dtype=torch.float32, device=device)
-        return buf
+        return buf[:B]
 
     def fft_input_view(self, B, X, Y, Z, device):
         """(B,cin,X,Y,Z) view of the zero-padded input buffer of the frequency-domain opening conv: a producer
