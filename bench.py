@@ -177,6 +177,12 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     def k_planar():
         _lib.unproject_fwd(planar, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
 
+    with torch.no_grad():
+        fft_view = model.v2v_net.input_view(B, *cube, dev) if hasattr(model.v2v_net, "input_view") else None
+
+    def k_strided():              # the same kernel writing straight into the FFT conv's zero-padded input (as in the step)
+        _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False, out=fft_view)
+
     scratch = torch.empty_like(packed)
 
     def k_pack():
@@ -186,6 +192,8 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     t_brick = event_time_ms(k_brick_cl, iters, dev)
     t_planar = event_time_ms(k_planar, max(10, iters // 10), dev)
     t_pack = event_time_ms(k_pack, iters, dev)
+    with torch.no_grad():
+        t_strided = event_time_ms(k_strided, iters, dev) if fft_view is not None else None
     # algorithmic bytes per launch: read every heat-map element once, write cubes
     # once; `grids` is not requested by the root net so its 3N term is dropped.
     alg_bytes = 4.0 * B * (V * J * h * w + J * N)
@@ -201,6 +209,7 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
                 if not planar_input else "re-tiling pass (pack_nhwc_kernel<16>) + unprojection kernel: planar hand-over",
         "path_frac": round(alg_bytes / (path * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "path_us_planar_handover": round((t_k + t_pack) * 1e3, 2),
+        "kernel_us_strided_result": None if t_strided is None else round(t_strided * 1e3, 2),
         "other_kernels_us": {"pack_nhwc_kernel<16>": round(t_pack * 1e3, 2),
                              "unproject_brick_kernel<16,true> (channels-last result)": round(t_brick * 1e3, 2),
                              "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},

@@ -439,9 +439,8 @@ class _FoldedV2V:
         if self.net.winograd and self._is_cl(x) and x.is_cuda:
             B, C, X, Y, Z = x.shape
             O = w.shape[0]
-            y = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, C), w.reshape(O, C).t())
-            if bias is not None:
-                y = y + bias
+            x2 = x.permute(0, 2, 3, 4, 1).reshape(-1, C)
+            y = torch.matmul(x2, w.reshape(O, C).t()) if bias is None else torch.addmm(bias, x2, w.reshape(O, C).t())
             return y.view(B, X, Y, Z, O).permute(0, 4, 1, 2, 3)
         return F.conv3d(x, w, bias, 1, 0)
 

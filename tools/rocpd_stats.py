@@ -48,6 +48,14 @@ def main():
     rows = load(path)
     print(f"# rocprofv3 kernel trace summary ({os.path.basename(path.rstrip('/'))}): {len(rows)} dispatches")
     table([r for r in rows if "sp3d" in r[0]], "sp3d kernels (all dispatches)")
+    # The unprojection kernel is launched in two contexts: inside the step (behind the previous step's V2V: cold L2 /
+    # Infinity Cache) and back to back in bench.py's roofline leg (the `roofline.kernel_us` of the bench line).
+    b2b = [rows[i] for i in range(1, len(rows)) if "unproject" in rows[i][0] and rows[i - 1][0] == rows[i][0]]
+    ins = [rows[i] for i in range(1, len(rows)) if "unproject" in rows[i][0] and rows[i - 1][0] != rows[i][0]]
+    if b2b:
+        table(b2b, "unprojection kernels, back-to-back launches only (bench.py roofline leg: warm inputs)")
+    if ins:
+        table(ins, "unprojection kernels, launches behind another kernel (inside the step: cold caches)")
     ends = [i for i, r in enumerate(rows) if r[0].startswith(step_end)]
     if len(ends) >= 3:
         a, b = ends[-2], ends[-1]
