@@ -63,6 +63,15 @@ def main():
         span = (step[-1][2] - step[0][1]) / 1e3
         busy = sum(e - s for _, s, e in step) / 1e3
         table(step, f"last steady-state step: {len(step)} kernels, span {span:.1f} us, GPU-busy {busy:.1f} us")
+        if "--sequence" in sys.argv:
+            print("\n### last steady-state step in launch order\n")
+            print("| # | start us | dur us | gap before us | kernel |")
+            print("|---:|---:|---:|---:|---|")
+            t0, prev = step[0][1], None
+            for i, (n, s_, e_) in enumerate(step):
+                gap = 0.0 if prev is None else (s_ - prev) / 1e3
+                print(f"| {i} | {(s_ - t0) / 1e3:.1f} | {(e_ - s_) / 1e3:.1f} | {gap:.1f} | `{n[:90]}` |")
+                prev = e_
     table(rows, "all kernels (includes MIOpen find-mode warm-up)", top=15)
 
 
