@@ -210,6 +210,15 @@ int sp3d_channel_shift_act(float *y, const float *shift, const float *residual, 
                            int64_t inner, int channels_last, void *stream);
 
 /*
+ * First node of a HIP-graphed step: copy slot (*counter % R) of a PINNED HOST ring `ring[R][n]` (device-accessible
+ * pointer) into the device buffer `dst[n]`, then ++*counter (`counter`: device uint32, zero before the first launch).
+ * Lets every replay of one captured graph consume a fresh per-batch camera table (project_layer.py:64-75's per-call
+ * host data) without a host->device copy command between graph launches.  The host writes slot t % R before launching
+ * replay t and must not rewrite a slot before the replay that reads it has finished.
+ */
+int sp3d_fetch_ring(const float *ring, float *dst, uint32_t *counter, int R, int n, void *stream);
+
+/*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D
  *                                       Gaussian); gx/gy/gz are the fp32 voxel-centre coordinates per axis

@@ -27,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
@@ -280,6 +280,19 @@ def soft_argmax_grid(x: torch.Tensor, centers: torch.Tensor, grid_size, cube_siz
     check(lib.sp3d_soft_argmax_grid(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(), P, J,
                                     float(beta), _stream(x.device)), "sp3d_soft_argmax_grid")
     return out
+
+
+def fetch_ring(ring: torch.Tensor, dst: torch.Tensor, counter: torch.Tensor):
+    """graph-capturable: dst <- ring[counter % R] (ring: PINNED host tensor (R, ...)), counter += 1 (device int32)"""
+    lib = load()
+    lib.sp3d_fetch_ring.restype = C.c_int
+    lib.sp3d_fetch_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert ring.is_pinned() and ring.dtype == torch.float32 and dst.is_cuda and counter.is_cuda
+    R = int(ring.shape[0])
+    n = ring[0].numel()
+    assert dst.numel() == n and dst.is_contiguous() and ring.is_contiguous()
+    check(lib.sp3d_fetch_ring(ring.data_ptr(), dst.data_ptr(), counter.data_ptr(), R, n, _stream(dst.device)),
+          "sp3d_fetch_ring")
 
 
 def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual: Optional[torch.Tensor] = None):

@@ -125,3 +125,39 @@ extern "C" int sp3d_upsample2x_scatter(const float *G, float *out, const float *
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// sp3d_fetch_ring: the per-batch camera table of a HIP-GRAPHED step.
+//
+// A captured step cannot take a different source address per replay, and an asynchronous host->device copy enqueued
+// between two graph launches costs ~90 us of idle GPU (copy-command latency between the two graphs,
+// profiles/r02_bench_kernel_stats.md).  Instead the graph's first node is this one-workgroup kernel: the host writes
+// the table of step t into slot t % R of a PINNED host ring before launching replay t; the kernel keeps its own step
+// counter in device memory, reads slot counter % R straight from host memory (2.5 KB over PCIe, a few us) into the
+// fixed device table the other kernels read, and increments the counter.  Replays execute in stream order, so replay t
+// always reads slot t % R; the host may run R - 1 launches ahead (it waits on the event of replay t - R before
+// rewriting a slot).
+// ------------------------------------------------------------------------------------------
+namespace sp3d {
+__global__ __launch_bounds__(256) void fetch_ring_kernel(const float *__restrict__ ring, float *__restrict__ dst,
+                                                        unsigned int *__restrict__ counter, int R, int n)
+{
+    __shared__ unsigned int slot;
+    if (threadIdx.x == 0) slot = *counter % (unsigned int)R;
+    __syncthreads();
+    const volatile float *src = ring + (size_t)slot * n;       // host memory: uncached reads
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = *counter + 1u;
+}
+} // namespace sp3d
+
+extern "C" int sp3d_fetch_ring(const float *ring, float *dst, uint32_t *counter, int R, int n, void *stream)
+{
+    if (R <= 0 || n <= 0) return SP3D_EINVAL;
+    if (!ring || !dst || !counter) return SP3D_ENULL;
+    hipLaunchKernelGGL(sp3d::fetch_ring_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ring, dst, counter, R, n);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}

@@ -232,3 +232,42 @@ def test_reprojection_heatmaps_gradient_reaches_the_3d_joints():
     gs = max(1e-12, float(j64.grad.abs().max()))
     assert float((jg.grad.cpu().double() - j64.grad).abs().max()) <= 2e-3 * gs
     assert float(jg.grad[1, 2].abs().max()) == 0.0                                  # person beyond the count
+
+
+@pytest.mark.gpu
+def test_graphed_rootnet_follows_changing_meta_and_leaves_the_net_untouched():
+    """GraphedRootNet: every replay consumes the camera table of ITS call (pinned ring + sp3d_fetch_ring as first graph
+    node), also when the host runs several launches ahead; eager calls on the same net keep using their own meta."""
+    from selfpose3d_amd import synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
+    from selfpose3d_amd.graphs import GraphedRootNet
+    dev = torch.device("cuda:0")
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[384, 288], NETWORK__HEATMAP_SIZE=[96, 72],
+                      MULTI_PERSON__INITIAL_CUBE_SIZE=[24, 24, 8])
+    B, V, J = 2, 4, 15
+    metas = [syn.make_meta(B, V, (384, 288)),
+             syn.make_meta(B, V, (384, 288), rotations=[10.0, -20.0], scale_mults=[1.2, 0.9], ssv_style=True),
+             syn.random_meta(B, V, (384, 288), seed=4, augment=True)]
+    hms, _ = syn.people_heatmaps(B, V, J, 72, 96, (384, 288), seed=11)
+    hms = [h.to(dev) for h in hms]
+    net = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=5, scale=0.05)
+    net.eval().to(dev)
+    net.use_channels_last(True)
+    with torch.no_grad():
+        eager = [tuple(t.clone() for t in net(hms, m)) for m in metas]
+        graphed = GraphedRootNet(net, hms, metas[0])
+        # launch a burst without synchronising in between (host ahead of the GPU), meta changing every call
+        outs = []
+        for k in range(9):
+            rc, gc = graphed(metas[k % 3])
+            outs.append((k % 3, rc.clone(), gc.clone()))
+        torch.cuda.synchronize()
+        for which, rc, gc in outs:
+            assert float((rc - eager[which][0]).abs().max()) <= 2e-4 * max(1.0, float(eager[which][0].abs().max())), which
+            assert torch.equal(gc[:, :3, :3], eager[which][1][:, :3, :3]), which
+        # the net itself is untouched: an eager call with another meta gives that meta's answer
+        again = net(hms, metas[2])
+        assert torch.equal(again[0], eager[2][0]) or float((again[0] - eager[2][0]).abs().max()) <= 1e-5
+        assert net.project_layer._static_cam is None and net.project_layer.cache_packs is True
