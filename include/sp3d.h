@@ -185,6 +185,11 @@ int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int6
 int64_t sp3d_nms_topk_workspace_bytes(int B, int X, int Y, int Z, int k);
 int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
                   const float *grid_center, float *vals, int64_t *idx, float *locs, void *workspace, void *stream);
+/* the same plus ProposalLayer.forward in eval (cuboid_proposal_net.py:54-83, threshold rule :79-81) in the merge kernel:
+ * grid_centers (B,k,5) = [x, y, z mm, (score > threshold) - 1, score]  (locs must be given; NULL = not wanted) */
+int sp3d_nms_proposals(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
+                       const float *grid_center, float threshold, float *vals, int64_t *idx, float *locs,
+                       float *grid_centers, void *workspace, void *stream);
 
 /*
  * SoftArgmaxLayer.forward (lib/models/pose_regression_net.py:19-28):

@@ -26,7 +26,7 @@ ABI_VERSION = 1
 
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
-    "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
+    "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
@@ -229,6 +229,29 @@ def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: 
                                         Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
     check(rc, "sp3d_unproject_bwd")
     return gviews
+
+
+def nms_proposals(root_cubes: torch.Tensor, k: int, grid_size, grid_center, threshold: float) -> torch.Tensor:
+    """(B,X,Y,Z) -> grid_centers (B,k,5) = [x,y,z mm, (score > threshold) - 1, score]: NMS, top-k, index -> mm and the
+    eval-mode proposal flags in the same two launches (no torch glue kernels)."""
+    lib = load()
+    lib.sp3d_nms_proposals.restype = C.c_int
+    lib.sp3d_nms_proposals.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 6
+    _require_cuda(root_cubes, "root_cubes")
+    rc_ = root_cubes.contiguous().float()
+    B, X, Y, Z = rc_.shape
+    dev = rc_.device
+    out = torch.empty((B, k, 5), dtype=torch.float32, device=dev)
+    scratch = torch.empty((B * k * (1 + 3) * 4 + B * k * 3 * 8,), dtype=torch.uint8, device=dev)
+    vals = scratch[:B * k * 4].view(torch.float32)
+    locs = scratch[B * k * 4:B * k * 16].view(torch.float32)
+    idx = scratch[B * k * 16:].view(torch.int64)
+    nbytes = lib.sp3d_nms_topk_workspace_bytes(B, X, Y, Z, k)
+    ws = torch.empty((max(int(nbytes), 8),), dtype=torch.uint8, device=dev)
+    rc = lib.sp3d_nms_proposals(rc_.data_ptr(), B, X, Y, Z, k, _f3(grid_size), _f3(grid_center), C.c_float(float(threshold)),
+                                vals.data_ptr(), idx.data_ptr(), locs.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream(dev))
+    check(rc, "sp3d_nms_proposals")
+    return out
 
 
 def nms_topk(root_cubes: torch.Tensor, k: int, grid_size=None, grid_center=None):

@@ -124,7 +124,8 @@ constexpr int MERGE_PER_THREAD = 16;
 __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict__ ws, int ncand, int X, int Y, int Z,
                                                                int k, float Lx, float Ly, float Lz, float cx, float cy,
                                                                float cz, float *__restrict__ vals,
-                                                               int64_t *__restrict__ idx, float *__restrict__ locs)
+                                                               int64_t *__restrict__ idx, float *__restrict__ locs,
+                                                               float *__restrict__ gcent, float threshold)
 {
     __shared__ float sv[NMS_THREADS / 64];
     __shared__ int si[NMS_THREADS / 64];
@@ -175,6 +176,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict
                 lp[0] = ((float)ix / (float)(X - 1) * Lx + cx) - Lx / 2.0f;
                 lp[1] = ((float)iy / (float)(Y - 1) * Ly + cy) - Ly / 2.0f;
                 lp[2] = ((float)iz / (float)(Z - 1) * Lz + cz) - Lz / 2.0f;
+                if (gcent) {   // ProposalLayer.forward in eval (cuboid_proposal_net.py:62-81): [x,y,z, (score>thr)-1, score]
+                    float *gp = gcent + ((size_t)b * k + t) * 5;
+                    const float v = win.i == 0x7fffffff ? 0.0f : win.v;
+                    gp[0] = lp[0]; gp[1] = lp[1]; gp[2] = lp[2];
+                    gp[3] = (v > threshold ? 1.0f : 0.0f) - 1.0f;
+                    gp[4] = v;
+                }
             }
         }
     }
@@ -276,13 +284,14 @@ extern "C" int64_t sp3d_nms_topk_workspace_bytes(int B, int X, int Y, int Z, int
     return (int64_t)B * nchunks * k * (int64_t)sizeof(Cand);
 }
 
-extern "C" int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
-                             const float *grid_center, float *vals, int64_t *idx, float *locs, void *workspace,
-                             void *stream)
+extern "C" int sp3d_nms_proposals(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
+                                  const float *grid_center, float threshold, float *vals, int64_t *idx, float *locs,
+                                  float *grid_centers, void *workspace, void *stream)
 {
     if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || k <= 0 || k > SP3D_MAX_TOPK) return SP3D_EINVAL;
     if (!root_cubes || !vals || !idx || !workspace) return SP3D_ENULL;
     if (locs && (!grid_size || !grid_center)) return SP3D_ENULL;
+    if (grid_centers && !locs) return SP3D_ENULL;
     const int64_t N = (int64_t)X * Y * Z;
     if (N > 0x7ffffffe) return SP3D_ERANGE;
     const int nchunks = (int)((N + NMS_CHUNK - 1) / NMS_CHUNK);
@@ -294,9 +303,17 @@ extern "C" int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z
     const float L[3] = {locs ? grid_size[0] : 0.f, locs ? grid_size[1] : 0.f, locs ? grid_size[2] : 0.f};
     const float C[3] = {locs ? grid_center[0] : 0.f, locs ? grid_center[1] : 0.f, locs ? grid_center[2] : 0.f};
     hipLaunchKernelGGL(nms_merge_kernel, dim3(B), dim3(NMS_THREADS), 0, s, ws, nchunks * k, X, Y, Z, k, L[0], L[1],
-                       L[2], C[0], C[1], C[2], vals, idx, locs);
+                       L[2], C[0], C[1], C[2], vals, idx, locs, grid_centers, threshold);
     e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_nms_topk(const float *root_cubes, int B, int X, int Y, int Z, int k, const float *grid_size,
+                             const float *grid_center, float *vals, int64_t *idx, float *locs, void *workspace,
+                             void *stream)
+{
+    return sp3d_nms_proposals(root_cubes, B, X, Y, Z, k, grid_size, grid_center, 0.0f, vals, idx, locs, nullptr, workspace,
+                              stream);
 }
 
 extern "C" int sp3d_soft_argmax(const float *x, const float *grids, float *out, int Bv, int J, int64_t N, float beta,

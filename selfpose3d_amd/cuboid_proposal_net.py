@@ -37,6 +37,10 @@ class ProposalLayer(nn.Module):
 
     def forward(self, root_cubes, meta):
         B = root_cubes.shape[0]
+        if root_cubes.is_cuda and not (self.training and ("roots_3d" in meta[0] and "num_person" in meta[0])):
+            # eval: [x,y,z, (score > THRESHOLD) - 1, score] straight from the NMS merge kernel
+            from . import _lib
+            return _lib.nms_proposals(root_cubes.detach(), self.num_cand, self.grid_size, self.grid_center, self.threshold)
         vals, _idx, locs = nms_with_locations(root_cubes, self.num_cand, self.grid_size, self.grid_center)
         grid_centers = torch.zeros(B, self.num_cand, 5, device=root_cubes.device)
         grid_centers[:, :, 0:3] = locs

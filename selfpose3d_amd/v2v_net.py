@@ -392,7 +392,9 @@ class _FoldedV2V:
             wp = torch.zeros(tuple(w0.shape[:2]) + S, dtype=torch.float32, device=w0.device)
             wp[:, :, :k, :k, :k] = w0.float()
             wp = torch.roll(wp, shifts=(-(k // 2),) * 3, dims=(2, 3, 4))
-            self.t[wkey] = torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj().contiguous()   # correlation
+            # correlation (conj); the inverse transform's 1/N is folded in here, so irfftn runs unnormalised
+            self.t[wkey] = (torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj() /
+                            float(S[0] * S[1] * S[2])).contiguous()
         if getattr(x, "_sp3d_fft_shape", None) == S and x.shape[1] == cin and \
                 x.stride() == (x.stride(0), S[0] * S[1] * S[2], S[1] * S[2], S[2], 1):
             # x IS the signal corner of a zero-padded buffer (fft_input_view / fft_input_views): no pad/copy pass
@@ -401,7 +403,7 @@ class _FoldedV2V:
             buf = self._fft_buffer(B, cin, S, x.device)
             buf[:, :, :X, :Y, :Z].copy_(x[:, :cin])                             # borders stay zero across calls
         Yf = _lib.freq_contract(torch.fft.rfftn(buf, dim=(2, 3, 4)), self.t[wkey])
-        y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4))[:, :, :X, :Y, :Z]
+        y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4), norm="forward")[:, :, :X, :Y, :Z]      # no scaling pass (in Wf)
         w1 = self.t["front_res"][0]             # a 3x3x3 weight tells the layout the conv stack runs in
         cl = w1.is_contiguous(memory_format=torch.channels_last_3d) and not w1.is_contiguous()
         y = y.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
