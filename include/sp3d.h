@@ -223,6 +223,10 @@ int sp3d_channel_shift_act(float *y, const float *shift, const float *residual, 
  */
 int sp3d_fetch_ring(const float *ring, float *dst, uint32_t *counter, int R, int n, void *stream);
 
+/* MaxPool3d(kernel 2, stride 2) of the V2V encoder (v2v_net.py:48-54) on channels-last activations:
+ * x (B,X,Y,Z,C) -> y (B,X/2,Y/2,Z/2,C); X,Y,Z even, C % 4 == 0; NaN propagates like torch.max_pool3d. */
+int sp3d_maxpool2x_cl(const float *x, float *y, int B, int X, int Y, int Z, int C, void *stream);
+
 /*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D

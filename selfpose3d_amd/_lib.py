@@ -27,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
@@ -316,6 +316,17 @@ def fetch_ring(ring: torch.Tensor, dst: torch.Tensor, counter: torch.Tensor):
     assert dst.numel() == n and dst.is_contiguous() and ring.is_contiguous()
     check(lib.sp3d_fetch_ring(ring.data_ptr(), dst.data_ptr(), counter.data_ptr(), R, n, _stream(dst.device)),
           "sp3d_fetch_ring")
+
+
+def maxpool2x(x: torch.Tensor) -> torch.Tensor:
+    """MaxPool3d(2,2) of a channels_last_3d tensor (B,C,X,Y,Z) -> channels_last_3d (B,C,X/2,Y/2,Z/2)"""
+    lib = load()
+    lib.sp3d_maxpool2x_cl.restype = C.c_int
+    lib.sp3d_maxpool2x_cl.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    y = torch.empty((B, X // 2, Y // 2, Z // 2, Cc), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    check(lib.sp3d_maxpool2x_cl(x.data_ptr(), y.data_ptr(), B, X, Y, Z, Cc, _stream(x.device)), "sp3d_maxpool2x_cl")
+    return y
 
 
 def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual: Optional[torch.Tensor] = None):

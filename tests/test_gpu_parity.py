@@ -834,3 +834,18 @@ def test_deterministic_backward_is_bit_reproducible(dev):
         assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
         ref = case.g["grad_hm"]
         assert np.abs(runs[0].cpu().numpy() - ref).max() <= 2e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_maxpool2x_channels_last_equals_torch(dev):
+    from selfpose3d_amd import _lib
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for shape in ((2, 32, 16, 12, 8), (1, 64, 40, 40, 10), (3, 4, 2, 2, 2)):
+        x0 = torch.randn(shape, generator=g)
+        x0.view(-1)[::97] = float("nan")                                  # NaN propagates like torch.max_pool3d
+        x = x0.to(dev).contiguous(memory_format=torch.channels_last_3d)
+        got = _lib.maxpool2x(x)
+        ref = F.max_pool3d(x, 2, 2)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
