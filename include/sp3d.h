@@ -54,7 +54,8 @@ enum {
     SP3D_EINVAL = -1,        /* a dimension <= 0, V > SP3D_MAX_VIEWS, unknown layout ...  */
     SP3D_ENULL = -2,         /* a required pointer is NULL                                */
     SP3D_ERANGE = -3,        /* X*Y*Z, B*J*N or the launch grid overflows 32-bit limits   */
-    SP3D_EUNSUPPORTED = -4   /* combination not implemented (e.g. Jp not a multiple of 4) */
+    SP3D_EUNSUPPORTED = -4,  /* combination not implemented (e.g. Jp not a multiple of 4) */
+    SP3D_EFFT = -5           /* hipFFT refused to build or run a plan                      */
 };
 
 /* heat-map layouts accepted by the unprojection kernels (per-view pointers in both) */
@@ -226,6 +227,19 @@ int sp3d_fetch_ring(const float *ring, float *dst, uint32_t *counter, int R, int
 /* MaxPool3d(kernel 2, stride 2) of the V2V encoder (v2v_net.py:48-54) on channels-last activations:
  * x (B,X,Y,Z,C) -> y (B,X/2,Y/2,Z/2,C); X,Y,Z even, C % 4 == 0; NaN propagates like torch.max_pool3d. */
 int sp3d_maxpool2x_cl(const float *x, float *y, int B, int X, int Y, int Z, int C, void *stream);
+
+/* Tail of the frequency-domain 7x7x7 opening conv (replaces v2v_net.py:10-20's BatchNorm+ReLU after the conv): crop the
+ * [0:X,0:Y,0:Z] corner of planar volumes src (B,C,SX,SY,SZ), add shift[c] (folded BN), optional ReLU, and write
+ * channels-last dst (B,X,Y,Z,C) in one pass.  C % 4 == 0, Z % 4 == 0, SZ % 4 == 0, 16-byte aligned pointers. */
+int sp3d_crop_shift_act_cl(const float *src, float *dst, const float *shift, int B, int C, int X, int Y, int Z, int SX, int SY,
+                           int SZ, int relu, void *stream);
+
+/* Batched 3-D real transforms (unnormalised, like rfftn / irfftn(norm="forward")) of the frequency-domain opening conv:
+ *   sp3d_rfft3d : real in (batch,SX,SY,SZ) dense -> complex out (batch,SX,SY,SZ/2+1) interleaved (re,im); `in` is preserved
+ *   sp3d_irfft3d: complex in (batch,SX,SY,SZ/2+1) -> real out (batch,SX,SY,SZ); `in` is SCRATCH (contents destroyed)
+ * hipFFT plans cached per (device, direction, batch, SX,SY,SZ); the first call of a shape allocates (not capturable). */
+int sp3d_rfft3d(const float *in, float *out, int batch, int SX, int SY, int SZ, void *stream);
+int sp3d_irfft3d(float *in, float *out, int batch, int SX, int SY, int SZ, void *stream);
 
 /*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):

@@ -27,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
@@ -326,6 +326,53 @@ def maxpool2x(x: torch.Tensor) -> torch.Tensor:
     B, Cc, X, Y, Z = (int(v) for v in x.shape)
     y = torch.empty((B, X // 2, Y // 2, Z // 2, Cc), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     check(lib.sp3d_maxpool2x_cl(x.data_ptr(), y.data_ptr(), B, X, Y, Z, Cc, _stream(x.device)), "sp3d_maxpool2x_cl")
+    return y
+
+
+def rfft3d(x: torch.Tensor) -> torch.Tensor:
+    """unnormalised rFFT over the last three dims of a dense fp32 (..., SX,SY,SZ) tensor -> complex64 (..., SX,SY,SZ//2+1);
+    x is only read (no defensive clone, unlike torch.fft.rfftn on ROCm)"""
+    lib = load()
+    _require_cuda(x, "x")
+    if not x.is_contiguous() or x.dtype != torch.float32 or x.dim() < 3:
+        raise Sp3dError("rfft3d: x must be a dense fp32 tensor with >= 3 dims")
+    lib.sp3d_rfft3d.restype = C.c_int
+    lib.sp3d_rfft3d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    SX, SY, SZ = (int(v) for v in x.shape[-3:])
+    batch = int(x.numel() // (SX * SY * SZ))
+    out = torch.empty(tuple(x.shape[:-1]) + (SZ // 2 + 1,), dtype=torch.complex64, device=x.device)
+    check(lib.sp3d_rfft3d(x.data_ptr(), out.data_ptr(), batch, SX, SY, SZ, _stream(x.device)), "sp3d_rfft3d")
+    return out
+
+
+def irfft3d_(spec: torch.Tensor, SZ: int) -> torch.Tensor:
+    """unnormalised inverse of rfft3d: complex64 (..., SX,SY,SZ//2+1) -> fp32 (..., SX,SY,SZ).  `spec` is scratch
+    afterwards (the C2R plan may overwrite it)"""
+    lib = load()
+    _require_cuda(spec, "spec")
+    if not spec.is_contiguous() or spec.dtype != torch.complex64 or spec.dim() < 3 or spec.shape[-1] != SZ // 2 + 1:
+        raise Sp3dError("irfft3d_: spec must be a dense complex64 (..., SX,SY,SZ//2+1) tensor")
+    lib.sp3d_irfft3d.restype = C.c_int
+    lib.sp3d_irfft3d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    SX, SY = (int(v) for v in spec.shape[-3:-1])
+    batch = int(spec.numel() // (SX * SY * (SZ // 2 + 1)))
+    out = torch.empty(tuple(spec.shape[:-1]) + (int(SZ),), dtype=torch.float32, device=spec.device)
+    check(lib.sp3d_irfft3d(spec.data_ptr(), out.data_ptr(), batch, SX, SY, int(SZ), _stream(spec.device)), "sp3d_irfft3d")
+    return out
+
+
+def crop_shift_act_cl(src: torch.Tensor, X: int, Y: int, Z: int, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """planar (B,C,SX,SY,SZ) -> channels_last_3d (B,C,X,Y,Z) = act(src[:, :, :X, :Y, :Z] + shift[c]) in one pass"""
+    lib = load()
+    _require_cuda(src, "src")
+    lib.sp3d_crop_shift_act_cl.restype = C.c_int
+    lib.sp3d_crop_shift_act_cl.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_void_p]
+    if not src.is_contiguous() or src.dtype != torch.float32:
+        raise Sp3dError("crop_shift_act_cl: src must be a dense fp32 (B,C,SX,SY,SZ) tensor")
+    B, Cc, SX, SY, SZ = (int(v) for v in src.shape)
+    y = torch.empty((B, X, Y, Z, Cc), dtype=torch.float32, device=src.device).permute(0, 4, 1, 2, 3)
+    check(lib.sp3d_crop_shift_act_cl(src.data_ptr(), y.data_ptr(), shift.data_ptr(), B, Cc, X, Y, Z, SX, SY, SZ,
+                                     1 if relu else 0, _stream(src.device)), "sp3d_crop_shift_act_cl")
     return y
 
 

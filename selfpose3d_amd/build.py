@@ -13,12 +13,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip"]
+SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip", "sp3d_fft.hip"]
 HEADERS = ["sp3d_device.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
 LIB = os.path.join(HERE, "libsp3d.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
+LINK = ["-L/opt/rocm/lib", "-lhipfft"]      # torch loads its own libhipfft.so.0 first; the loader reuses that instance
 
 
 def needs_build() -> bool:
@@ -31,14 +32,14 @@ def needs_build() -> bool:
 
 def build_variant(out: str, extra_flags=()) -> str:
     """measurement builds (e.g. -DSP3D_TIMELINE for tools/wave_timeline.py); never loaded by the package"""
-    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out])
+    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", out])
     return out
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -193,6 +193,49 @@ __global__ __launch_bounds__(256) void maxpool2x_cl_kernel(const float *__restri
         *reinterpret_cast<float4 *>(y + i * 4) = m;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// crop + shift (+ReLU) + planar -> channels-last, the tail of the frequency-domain opening conv: the inverse transform
+// leaves (B,C,SX,SY,SZ) planar volumes whose [0:X,0:Y,0:Z] corner is the result.  torch needs a strided copy (crop +
+// layout change) and then the in-place epilogue; this is one pass: a work-group takes NY consecutive y columns of one
+// (b,x), reads 16-byte pieces of the z runs of every channel, transposes through LDS and writes NY*Z*C contiguous floats.
+constexpr int CROP_NY = 4;
+__global__ __launch_bounds__(256) void crop_shift_act_cl_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               const float *__restrict__ shift, int X, int Y, int Z, int C,
+                                                               int SX, int SY, int SZ, int relu)
+{
+    extern __shared__ float lds[];                      // [CROP_NY][Z][C + 4]
+    const int P = C + 4, Z4 = Z >> 2, C4 = C >> 2;
+    const int ygroups = (Y + CROP_NY - 1) / CROP_NY;
+    int r = blockIdx.x;
+    const int yg = r % ygroups; r /= ygroups;
+    const int x = r % X;
+    const int b = r / X;
+    const int y0 = yg * CROP_NY;
+    const int ny = min(CROP_NY, Y - y0);
+    const int per_col = C * Z4;
+    for (int e = threadIdx.x; e < ny * per_col; e += 256) {
+        const int col = e / per_col, q = e - col * per_col;
+        const int c = q / Z4, z4 = q - c * Z4;
+        const float4 v = *reinterpret_cast<const float4 *>(
+            src + ((((int64_t)b * C + c) * SX + x) * SY + (y0 + col)) * SZ + 4 * z4);
+        float *o = lds + ((col * Z) + 4 * z4) * P + c;
+        o[0] = v.x; o[P] = v.y; o[2 * P] = v.z; o[3 * P] = v.w;
+    }
+    __syncthreads();
+    float *out = dst + (((int64_t)b * X + x) * Y + y0) * Z * C;
+    for (int e = threadIdx.x; e < ny * Z * C4; e += 256) {
+        const int vox = e / C4, q = e - vox * C4;
+        float4 v = *reinterpret_cast<const float4 *>(lds + vox * P + 4 * q);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + 4 * q);
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        if (relu) {                                      // NaN propagates like torch.relu
+            v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y;
+            v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+        }
+        *reinterpret_cast<float4 *>(out + (int64_t)e * 4) = v;
+    }
+}
 } // namespace sp3d
 
 extern "C" int sp3d_maxpool2x_cl(const float *x, float *y, int B, int X, int Y, int Z, int C, void *stream)
@@ -204,6 +247,24 @@ extern "C" int sp3d_maxpool2x_cl(const float *x, float *y, int B, int X, int Y, 
     const int64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(sp3d::maxpool2x_cl_kernel, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
                        (hipStream_t)stream, x, y, B, X, Y, Z, C);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+
+extern "C" int sp3d_crop_shift_act_cl(const float *src, float *dst, const float *shift, int B, int C, int X, int Y, int Z,
+                                      int SX, int SY, int SZ, int relu, void *stream)
+{
+    if (B <= 0 || C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || SX < X || SY < Y || SZ < Z) return SP3D_EINVAL;
+    if (!src || !dst || !shift) return SP3D_ENULL;
+    if ((C & 3) || (Z & 3) || (SZ & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15))
+        return SP3D_EUNSUPPORTED;
+    const size_t lds = (size_t)sp3d::CROP_NY * Z * (C + 4) * sizeof(float);
+    if (lds > 64 * 1024) return SP3D_EUNSUPPORTED;
+    const int64_t blocks = (int64_t)B * X * ((Y + sp3d::CROP_NY - 1) / sp3d::CROP_NY);
+    if (blocks > 0x7fffffff) return SP3D_EINVAL;
+    hipLaunchKernelGGL(sp3d::crop_shift_act_cl_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, src, dst,
+                       shift, X, Y, Z, C, SX, SY, SZ, relu);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

@@ -1243,6 +1243,7 @@ extern "C" const char *sp3d_error_string(int code)
     case SP3D_ENULL: return "required pointer is NULL";
     case SP3D_ERANGE: return "size overflows 32-bit kernel indexing";
     case SP3D_EUNSUPPORTED: return "unsupported combination";
+    case SP3D_EFFT: return "hipFFT plan creation or execution failed";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown sp3d error";
     }
 }

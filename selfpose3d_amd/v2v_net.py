@@ -402,10 +402,15 @@ class _FoldedV2V:
         else:
             buf = self._fft_buffer(B, cin, S, x.device)
             buf[:, :, :X, :Y, :Z].copy_(x[:, :cin])                             # borders stay zero across calls
-        Yf = _lib.freq_contract(torch.fft.rfftn(buf, dim=(2, 3, 4)), self.t[wkey])
-        y = torch.fft.irfftn(Yf, s=S, dim=(2, 3, 4), norm="forward")[:, :, :X, :Y, :Z]      # no scaling pass (in Wf)
+        # cached hipFFT plans behind the C ABI: same rocFFT kernels (bit-identical spectra) as torch.fft.rfftn / irfftn,
+        # minus the defensive clones torch makes around every real transform on ROCm (3 x ~55 MB per root-net step)
+        Yf = _lib.freq_contract(_lib.rfft3d(buf), self.t[wkey])
+        y = _lib.irfft3d_(Yf, S[2])                                  # unnormalised (1/N is in Wf); Yf is scratch
         w1 = self.t["front_res"][0]             # a 3x3x3 weight tells the layout the conv stack runs in
         cl = w1.is_contiguous(memory_format=torch.channels_last_3d) and not w1.is_contiguous()
+        if cl and y.is_contiguous() and y.shape[1] % 4 == 0 and Z % 4 == 0 and 4 * Z * (y.shape[1] + 4) * 4 <= 65536:
+            return _lib.crop_shift_act_cl(y, X, Y, Z, s0, True)     # crop + layout change + epilogue in one pass
+        y = y[:, :, :X, :Y, :Z]
         y = y.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
         return _lib.channel_shift_act_(y, s0, 1)
 

@@ -849,3 +849,48 @@ def test_maxpool2x_channels_last_equals_torch(dev):
         assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
         assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
         assert torch.equal(torch.isnan(got), torch.isnan(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 24, 24, 12, 8, 20, 8), (1, 32, 9, 11, 64, 7, 10, 64), (3, 4, 6, 5, 4, 6, 5, 4)])
+def test_crop_shift_act_channels_last_equals_torch(shape):
+    """sp3d_crop_shift_act_cl == relu(src[..., :X,:Y,:Z] + shift) in channels_last_3d, bit for bit"""
+    from selfpose3d_amd import _lib
+    B, C, SX, SY, SZ, X, Y, Z = shape
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(B, C, SX, SY, SZ, generator=g).cuda()
+    src[0, 1, 0, 0, 0] = float("nan")
+    shift = torch.randn(C, generator=g).cuda()
+    for relu in (True, False):
+        got = _lib.crop_shift_act_cl(src, X, Y, Z, shift, relu)
+        want = src[:, :, :X, :Y, :Z] + shift.view(1, C, 1, 1, 1)
+        if relu:
+            want = torch.relu(want)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+        assert bool(torch.isnan(got[0, 1, 0, 0, 0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 24, 20, 12), (1, 2, 22, 18, 10), (5, 8, 8, 8)])
+def test_rfft3d_plans_equal_torch_fft(shape):
+    """sp3d_rfft3d / sp3d_irfft3d run the same rocFFT transforms as torch.fft.rfftn / irfftn(norm='forward'): equal
+    spectra (fp32 round-off), the input is preserved, round trip = N * x"""
+    from selfpose3d_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g).cuda()
+    x0 = x.clone()
+    dims = tuple(range(x.dim() - 3, x.dim()))
+    ref = torch.fft.rfftn(x, dim=dims)
+    got = _lib.rfft3d(x)
+    assert torch.equal(x, x0)
+    assert got.shape == ref.shape and got.dtype == torch.complex64
+    scale = float(torch.view_as_real(ref).abs().max())
+    assert float((torch.view_as_real(got) - torch.view_as_real(ref)).abs().max()) <= 2e-6 * scale
+    back = _lib.irfft3d_(got.clone(), shape[-1])
+    want = torch.fft.irfftn(ref, s=shape[-3:], dim=dims, norm="forward")
+    assert float((back - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    n = shape[-1] * shape[-2] * shape[-3]
+    assert float((back / n - x0).abs().max()) <= 1e-5
+    with pytest.raises(_lib.Sp3dError):
+        _lib.rfft3d(x.transpose(-1, -2))
