@@ -301,6 +301,12 @@ int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift
 int sp3d_upsample2x_scatter(const float *G, float *out, const float *shift, const float *skip, int64_t batch, int X, int Y,
                             int Z, int O, void *stream);
 
+/* The same scatter fused with the network's 1x1x1 output conv (v2v_net.py:128-133) for the LAST up-sampling layer, whose
+ * O = 32-channel result has no other consumer: head (batch,2X,2Y,2Z,J channels-last) = bout[j] + sum_o wout[j][o] *
+ * (relu(G + shift[o]) + skip[o]).  wout (J,32) row-major, O must be 32. */
+int sp3d_upsample2x_scatter_head(const float *G, float *head, const float *shift, const float *skip, const float *wout,
+                                 const float *bout, int64_t batch, int X, int Y, int Z, int O, int J, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -582,6 +582,30 @@ def upsample2x_(x: torch.Tensor, w_gemm: torch.Tensor, shift: torch.Tensor, skip
     check(lib.sp3d_upsample2x_scatter(G.data_ptr(), out.data_ptr(), shift.data_ptr(), skip.data_ptr(), B, X, Y, Z, O,
                                       _stream(x.device)), "sp3d_upsample2x_scatter")
     return out
+
+
+def upsample2x_head_(x: torch.Tensor, w_gemm: torch.Tensor, shift: torch.Tensor, skip: torch.Tensor, w_out: torch.Tensor,
+                     b_out: torch.Tensor) -> torch.Tensor:
+    """upsample2x_ fused with the 1x1x1 output conv that is its only consumer: returns (B,J,2X,2Y,2Z) as a permuted view
+    of a (B,2X,2Y,2Z,J) tensor (for J = 1 that is also the dense NCDHW tensor)"""
+    lib = load()
+    _require_cuda(x, "x")
+    lib.sp3d_upsample2x_scatter_head.restype = C.c_int
+    lib.sp3d_upsample2x_scatter_head.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_int] * 5 + [C.c_void_p]
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("upsample2x_head_: float32 channels_last_3d activations expected")
+    O = int(w_gemm.shape[1]) // 8
+    J = int(w_out.shape[0])
+    G = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, Cc), w_gemm)
+    if tuple(skip.shape) != (B, O, 2 * X, 2 * Y, 2 * Z) or not skip.is_contiguous(memory_format=torch.channels_last_3d):
+        skip = skip.contiguous(memory_format=torch.channels_last_3d)
+    wo = w_out.reshape(J, O).contiguous().float()
+    bo = (b_out if b_out is not None else torch.zeros(J, device=x.device)).contiguous().float()
+    head = torch.empty((B, 2 * X, 2 * Y, 2 * Z, J), dtype=torch.float32, device=x.device)
+    check(lib.sp3d_upsample2x_scatter_head(G.data_ptr(), head.data_ptr(), shift.data_ptr(), skip.data_ptr(), wo.data_ptr(),
+                                           bo.data_ptr(), B, X, Y, Z, O, J, _stream(x.device)), "sp3d_upsample2x_scatter_head")
+    return head.permute(0, 4, 1, 2, 3)
 
 
 class _RenderJoints(torch.autograd.Function):

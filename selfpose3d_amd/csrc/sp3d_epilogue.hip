@@ -109,6 +109,57 @@ __global__ __launch_bounds__(256) void upsample2x_scatter_kernel(const float *__
     }
 }
 
+
+// The LAST up-sampling layer feeds only the 1x1x1 output conv (v2v_net.py:128-133: output_layer(encoder_decoder(x))), so
+// its O = 32-channel result never needs to exist: the 8 lanes that hold one output voxel's channels (4 each) reduce
+//   head[j] = bias[j] + sum_o Wout[j][o] * (relu(G + shift[o]) + skip[o])
+// with three xor-shuffles per head channel and write (batch,2X,2Y,2Z,J) channels-last.  Saves the 65 MB write, the N = 1
+// (root net) / N = 15 GEMM that re-reads it, and the bias pass.
+__global__ __launch_bounds__(256) void upsample2x_scatter_head_kernel(const float *__restrict__ G, float *__restrict__ head,
+                                                                     const float *__restrict__ shift,
+                                                                     const float *__restrict__ skip,
+                                                                     const float *__restrict__ wout,
+                                                                     const float *__restrict__ bout, int64_t n_in, int X,
+                                                                     int Y, int Z, int J)
+{
+    constexpr int O = 32, q = 8;
+    const int64_t total = n_in * 8 * q;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int o4 = (int)(e & (q - 1));
+        int64_t r = e >> 3;
+        const int ijk = (int)(r & 7);
+        const int64_t n = r >> 3;
+        const int z = (int)(n % Z); int64_t m = n / Z;
+        const int y = (int)(m % Y); m /= Y;
+        const int x = (int)(m % X);
+        const int64_t b = m / X;
+        const int xo = 2 * x + (ijk >> 2), yo = 2 * y + ((ijk >> 1) & 1), zo = 2 * z + (ijk & 1);
+        const int64_t vox = ((b * (2 * X) + xo) * (2 * Y) + yo) * (2 * Z) + zo;
+        const float4 g = *reinterpret_cast<const float4 *>(G + (n * 8 + ijk) * O + 4 * o4);
+        const float4 s = *reinterpret_cast<const float4 *>(shift + 4 * o4);
+        const float4 k = *reinterpret_cast<const float4 *>(skip + vox * O + 4 * o4);
+        float4 v;
+        v.x = fmaxf(g.x + s.x, 0.0f) + k.x; v.y = fmaxf(g.y + s.y, 0.0f) + k.y;
+        v.z = fmaxf(g.z + s.z, 0.0f) + k.z; v.w = fmaxf(g.w + s.w, 0.0f) + k.w;
+        for (int j0 = 0; j0 < J; j0 += q) {
+            float mine = 0.0f;                                   // lane o4 keeps head channel j0 + o4
+#pragma unroll
+            for (int jj = 0; jj < q; ++jj) {
+                const int j = j0 + jj;
+                if (j >= J) break;                               // uniform
+                const float4 w = *reinterpret_cast<const float4 *>(wout + (int64_t)j * O + 4 * o4);
+                float p = fmaf(v.w, w.w, fmaf(v.z, w.z, fmaf(v.y, w.y, v.x * w.x)));
+                p += __shfl_xor(p, 1);
+                p += __shfl_xor(p, 2);
+                p += __shfl_xor(p, 4);
+                if (jj == o4) mine = p;
+            }
+            const int j = j0 + o4;
+            if (j < J) head[vox * J + j] = mine + bout[j];
+        }
+    }
+}
 } // namespace sp3d
 
 extern "C" int sp3d_upsample2x_scatter(const float *G, float *out, const float *shift, const float *skip, int64_t batch, int X,
@@ -122,6 +173,22 @@ extern "C" int sp3d_upsample2x_scatter(const float *G, float *out, const float *
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(sp3d::upsample2x_scatter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, out, shift, skip, n_in,
                        X, Y, Z, O);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+
+extern "C" int sp3d_upsample2x_scatter_head(const float *G, float *head, const float *shift, const float *skip, const float *wout,
+                                            const float *bout, int64_t batch, int X, int Y, int Z, int O, int J, void *stream)
+{
+    if (batch <= 0 || X <= 0 || Y <= 0 || Z <= 0 || O <= 0 || J <= 0) return SP3D_EINVAL;
+    if (!G || !head || !shift || !skip || !wout || !bout) return SP3D_ENULL;
+    if (O != 32) return SP3D_EUNSUPPORTED;
+    const int64_t n_in = batch * X * Y * Z;
+    const int64_t total = n_in * 8 * 8;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(sp3d::upsample2x_scatter_head_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, head, shift,
+                       skip, wout, bout, n_in, X, Y, Z, J);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

@@ -424,8 +424,12 @@ class _FoldedV2V:
         x = self._res(self._res(x, "mid_res"), "decoder_res2")
         x = self._up2x(x, "decoder_upsample2", skip2)
         x = self._res(x, "decoder_res1")
-        x = self._up2x(x, "decoder_upsample1", skip1)
         o = self.net.output_layer
+        wT, sT, wg = self.t["decoder_upsample1"]
+        if self.net.winograd and self._is_cl(x) and wg.is_cuda and wT.shape[1] == 32 and x.dtype == torch.float32:
+            # the last up-sampling layer's only consumer is the 1x1x1 output conv: one kernel, no 32-channel tensor
+            return _lib.upsample2x_head_(x, wg, sT, skip1, o.weight, o.bias)
+        x = self._up2x(x, "decoder_upsample1", skip1)
         return self._conv1(x, o.weight, o.bias)
 
     def _pool(self, x):

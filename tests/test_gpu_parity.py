@@ -894,3 +894,23 @@ def test_rfft3d_plans_equal_torch_fft(shape):
     assert float((back / n - x0).abs().max()) <= 1e-5
     with pytest.raises(_lib.Sp3dError):
         _lib.rfft3d(x.transpose(-1, -2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J", [1, 15, 9])
+def test_upsample_scatter_with_output_head(J):
+    """sp3d_upsample2x_scatter_head == 1x1x1 output conv applied to sp3d_upsample2x_scatter's result"""
+    from selfpose3d_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    B, Cin, X, Y, Z, O = 2, 64, 6, 5, 3, 32
+    x = torch.randn(B, Cin, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wg = (0.1 * torch.randn(Cin, 8 * O, generator=g)).cuda()
+    shift = torch.randn(O, generator=g).cuda()
+    skip = torch.randn(B, O, 2 * X, 2 * Y, 2 * Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wo = torch.randn(J, O, 1, 1, 1, generator=g).cuda()
+    bo = torch.randn(J, generator=g).cuda()
+    full = _lib.upsample2x_(x, wg, shift, skip)
+    want = torch.nn.functional.conv3d(full.double(), wo.double(), bo.double())
+    got = _lib.upsample2x_head_(x, wg, shift, skip, wo, bo)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())

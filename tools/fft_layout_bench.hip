@@ -1,0 +1,63 @@
+// fft_layout_bench.hip - rocFFT (through hipFFT) throughput of the opening conv's batched 3-D real transforms as a function
+// of the data layout: planar volumes (the layout the product uses) against channel-innermost volumes (istride = C,
+// idist = 1: what a channels-last unprojection result would hand over without a transpose).
+//   hipcc --offload-arch=gfx950 -O3 tools/fft_layout_bench.hip -lhipfft -o gpurun_out/fft_layout_bench
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+#include <cstdio>
+#include <vector>
+
+static float time_exec(hipfftHandle p, bool inverse, void *a, void *b, int reps, int execs, size_t in_step, size_t out_step)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&]() {
+        for (int i = 0; i < execs; ++i) {
+            if (inverse) hipfftExecC2R(p, (hipfftComplex *)((char *)a + i * in_step), (float *)((char *)b + i * out_step));
+            else hipfftExecR2C(p, (float *)((char *)a + i * in_step), (hipfftComplex *)((char *)b + i * out_step));
+        }
+    };
+    for (int i = 0; i < 3; ++i) run();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) run();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.f / reps;
+}
+
+int main()
+{
+    const int B = 4, C = 16, SX = 88, SY = 88, SZ = 28, SZc = SZ / 2 + 1;
+    const size_t nreal = (size_t)B * C * SX * SY * SZ, ncplx = (size_t)B * C * SX * SY * SZc;
+    float *re; hipfftComplex *cx;
+    hipMalloc(&re, nreal * 4); hipMalloc(&cx, ncplx * 8);
+    hipMemset(re, 0, nreal * 4); hipMemset(cx, 0, ncplx * 8);
+    int n[3] = {SX, SY, SZ};
+    {   // planar, one plan over all B*C volumes
+        hipfftHandle f, i;
+        hipfftPlanMany(&f, 3, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, B * C);
+        hipfftPlanMany(&i, 3, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, B * C);
+        printf("planar           fwd %.1f us   inv %.1f us\n", time_exec(f, false, re, cx, 50, 1, 0, 0), time_exec(i, true, cx, re, 50, 1, 0, 0));
+    }
+    {   // channel-innermost per sample: element (x,y,z,c) at ((x*SY+y)*SZ+z)*C + c; batch = C with dist 1; B execs
+        hipfftHandle f, i;
+        int ine[3] = {SX, SY, SZ}, one[3] = {SX, SY, SZc};
+        hipfftResult r1 = hipfftPlanMany(&f, 3, n, ine, C, 1, one, C, 1, HIPFFT_R2C, C);
+        hipfftResult r2 = hipfftPlanMany(&i, 3, n, one, C, 1, ine, C, 1, HIPFFT_C2R, C);
+        if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) printf("channel-innermost plan failed %d %d\n", r1, r2);
+        else printf("channel-inner x%d  fwd %.1f us   inv %.1f us\n", B,
+                    time_exec(f, false, re, cx, 50, B, (size_t)C * SX * SY * SZ * 4, (size_t)C * SX * SY * SZc * 8),
+                    time_exec(i, true, cx, re, 50, B, (size_t)C * SX * SY * SZc * 8, (size_t)C * SX * SY * SZ * 4));
+    }
+    {   // (b,c) innermost: element (x,y,z,b,c); one exec, batch = B*C with dist 1
+        hipfftHandle f, i;
+        int ine[3] = {SX, SY, SZ}, one[3] = {SX, SY, SZc};
+        hipfftResult r1 = hipfftPlanMany(&f, 3, n, ine, B * C, 1, one, B * C, 1, HIPFFT_R2C, B * C);
+        hipfftResult r2 = hipfftPlanMany(&i, 3, n, one, B * C, 1, ine, B * C, 1, HIPFFT_C2R, B * C);
+        if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) printf("batch-innermost plan failed %d %d\n", r1, r2);
+        else printf("batch-innermost   fwd %.1f us   inv %.1f us\n", time_exec(f, false, re, cx, 50, 1, 0, 0), time_exec(i, true, cx, re, 50, 1, 0, 0));
+    }
+    return 0;
+}
