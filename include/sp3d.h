@@ -241,6 +241,23 @@ int sp3d_crop_shift_act_cl(const float *src, float *dst, const float *shift, int
 int sp3d_rfft3d(const float *in, float *out, int batch, int SX, int SY, int SZ, void *stream);
 int sp3d_irfft3d(float *in, float *out, int batch, int SX, int SY, int SZ, void *stream);
 
+/* In-place batched 2-D complex transform of dense (batch,SX,SY) planes of interleaved (re,im) floats, unnormalised;
+ * inverse != 0: e^{+i} kernel.  Cached hipFFT plan per (device, batch, SX, SY). */
+int sp3d_cfft2d(float *data, int batch, int SX, int SY, int inverse, void *stream);
+
+/* z passes of the ROOT GRID's opening conv (v2v_net.py:113-117 on the 80x80x20 grid) as direct DFTs, spectrum layout
+ * (B, channels, SZ/2+1, SX, SY) so that the x,y passes are sp3d_cfft2d over batch = B*channels*(SZ/2+1) planes:
+ *   sp3d_zdft_fwd_cl: x (B,X,Y,Z,C) channels-last real (the unprojection's channels-last result, C = 16 with zero pad
+ *     channels) -> spec (B,Cout,SZ/2+1,SX,SY) complex = DFT_z of the rows zero-padded to SZ; rows with x >= X or y >= Y
+ *     are written as zeros; only channels c < Cout are kept.
+ *   sp3d_zdft_inv_cl: spec (B,O,SZ/2+1,SX,SY) complex (after the inverse x,y passes) -> y (B,X,Y,Z,O) channels-last real
+ *     = act(shift[o] + unnormalised C2R_z(spec))[0:X,0:Y,0:Z]; relu != 0: ReLU.
+ * Built for (Z,SZ) = (20,28), C = O = 16 (SP3D_EUNSUPPORTED otherwise: callers use sp3d_rfft3d / sp3d_irfft3d). */
+int sp3d_zdft_fwd_cl(const float *x, float *spec, int B, int C, int Cout, int X, int Y, int Z, int SX, int SY, int SZ,
+                     void *stream);
+int sp3d_zdft_inv_cl(const float *spec, float *y, const float *shift, int B, int O, int X, int Y, int Z, int SX, int SY, int SZ,
+                     int relu, void *stream);
+
 /*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D

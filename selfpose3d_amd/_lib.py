@@ -27,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
@@ -359,6 +359,54 @@ def irfft3d_(spec: torch.Tensor, SZ: int) -> torch.Tensor:
     out = torch.empty(tuple(spec.shape[:-1]) + (int(SZ),), dtype=torch.float32, device=spec.device)
     check(lib.sp3d_irfft3d(spec.data_ptr(), out.data_ptr(), batch, SX, SY, int(SZ), _stream(spec.device)), "sp3d_irfft3d")
     return out
+
+
+ZDFT_SHAPES = {(20, 28, 16)}       # (Z, SZ, channels) the direct z-DFT kernels are built for
+
+
+def cfft2d_(spec: torch.Tensor, inverse: bool) -> torch.Tensor:
+    """in-place unnormalised 2-D complex FFT over the last two dims of a dense complex64 tensor"""
+    lib = load()
+    _require_cuda(spec, "spec")
+    if not spec.is_contiguous() or spec.dtype != torch.complex64 or spec.dim() < 2:
+        raise Sp3dError("cfft2d_: dense complex64 tensor with >= 2 dims expected")
+    lib.sp3d_cfft2d.restype = C.c_int
+    lib.sp3d_cfft2d.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    SX, SY = int(spec.shape[-2]), int(spec.shape[-1])
+    check(lib.sp3d_cfft2d(spec.data_ptr(), int(spec.numel() // (SX * SY)), SX, SY, 1 if inverse else 0,
+                          _stream(spec.device)), "sp3d_cfft2d")
+    return spec
+
+
+def zdft_fwd_cl(x: torch.Tensor, cout: int, S) -> torch.Tensor:
+    """channels_last_3d (B,C,X,Y,Z) real -> (B,cout,SZ//2+1,SX,SY) complex64: z-DFT of the rows zero-padded to S"""
+    lib = load()
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if x.dtype != torch.float32 or not x.permute(0, 2, 3, 4, 1).is_contiguous():
+        raise Sp3dError("zdft_fwd_cl: dense fp32 channels_last_3d cubes expected")
+    lib.sp3d_zdft_fwd_cl.restype = C.c_int
+    lib.sp3d_zdft_fwd_cl.argtypes = [C.c_void_p] * 2 + [C.c_int] * 9 + [C.c_void_p]
+    SX, SY, SZ = (int(v) for v in S)
+    spec = torch.empty((B, int(cout), SZ // 2 + 1, SX, SY), dtype=torch.complex64, device=x.device)
+    check(lib.sp3d_zdft_fwd_cl(x.data_ptr(), spec.data_ptr(), B, Cc, int(cout), X, Y, Z, SX, SY, SZ, _stream(x.device)),
+          "sp3d_zdft_fwd_cl")
+    return spec
+
+
+def zdft_inv_cl(spec: torch.Tensor, X: int, Y: int, Z: int, SZ: int, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """(B,O,SZ//2+1,SX,SY) complex64 -> channels_last_3d (B,O,X,Y,Z) = act(shift[o] + unnormalised C2R along z)"""
+    lib = load()
+    _require_cuda(spec, "spec")
+    if not spec.is_contiguous() or spec.dtype != torch.complex64 or spec.dim() != 5 or spec.shape[2] != SZ // 2 + 1:
+        raise Sp3dError("zdft_inv_cl: dense complex64 (B,O,SZ//2+1,SX,SY) spectrum expected")
+    lib.sp3d_zdft_inv_cl.restype = C.c_int
+    lib.sp3d_zdft_inv_cl.argtypes = [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_void_p]
+    B, O, _, SX, SY = (int(v) for v in spec.shape)
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=spec.device).permute(0, 4, 1, 2, 3)
+    check(lib.sp3d_zdft_inv_cl(spec.data_ptr(), y.data_ptr(), shift.data_ptr(), B, O, X, Y, Z, SX, SY, int(SZ),
+                               1 if relu else 0, _stream(spec.device)), "sp3d_zdft_inv_cl")
+    return y
 
 
 def crop_shift_act_cl(src: torch.Tensor, X: int, Y: int, Z: int, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:

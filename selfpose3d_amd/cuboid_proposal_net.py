@@ -79,10 +79,14 @@ class CuboidProposalNet(nn.Module):
             hms = all_heatmaps
         planar = self.v2v_net.wants_planar_input() and hms[0].is_cuda      # FFT opening conv: plain J-channel cubes
         # ... which the unprojection kernel writes straight into that conv's zero-padded input buffer
-        out = self.v2v_net.input_view(hms[0].shape[0], *self.cube_size, hms[0].device) \
-            if planar and hms[0].shape[1] <= 16 and not torch.is_grad_enabled() else None
+        direct = planar and hms[0].shape[1] <= 16 and not torch.is_grad_enabled()
+        # ... on this grid as channels-last 16-channel cubes (its z pass is a HIP kernel that reads them as they are),
+        cl16 = direct and self.v2v_net.wants_channels_last_cubes(*self.cube_size)
+        # ... otherwise straight into that conv's zero-padded planar input buffer
+        out = self.v2v_net.input_view(hms[0].shape[0], *self.cube_size, hms[0].device) if direct and not cl16 else None
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
-                                                flip_xcoords=flip_xcoords, want_grids=False, pad_channels=not planar,
-                                                channels_last=self.channels_last and not planar, out=out)
+                                                flip_xcoords=flip_xcoords, want_grids=False,
+                                                pad_channels=cl16 or not planar,
+                                                channels_last=cl16 or (self.channels_last and not planar), out=out)
         root_cubes = self.v2v_net(cubes).squeeze(1)
         return root_cubes, self.proposal_layer(root_cubes, meta)

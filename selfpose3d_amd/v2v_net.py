@@ -336,6 +336,16 @@ class _FoldedV2V:
         x = _lib.channel_shift_act_(F.conv3d(x, w0, None, 1, 3), s0, 1)
         return self._tail(x)
 
+    def _zdft_ok(self, x, w0, S):
+        """the direct z-DFT form of the opening conv applies: channels-last 16-channel cubes of a (Z, SZ) the kernels are
+        built for, 16 output channels, channels-last conv stack behind it"""
+        from . import _lib
+        if not (getattr(self.net, "zdft", True) and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32):
+            return False
+        w1 = self.t["front_res"][0]
+        return bool((int(x.shape[4]), int(S[2]), int(x.shape[1])) in _lib.ZDFT_SHAPES and int(w0.shape[0]) == 16
+                    and int(w0.shape[1]) <= 16 and self._is_cl(w1) and x.permute(0, 2, 3, 4, 1).is_contiguous())
+
     _fft_len = staticmethod(fft_len)
 
     @classmethod
@@ -386,7 +396,7 @@ class _FoldedV2V:
         cin, k = int(w0.shape[1]), int(w0.shape[2])
         S = self._fft_shape(X, Y, Z, k)
         wkey = ("Wf", S)
-        if wkey not in self.t:
+        if wkey not in self.t and not (("Wz", S) in self.t and self._zdft_ok(x, w0, S)):
             # the signal sits at the ORIGIN of the padded buffer (so a producer can write 16-byte aligned rows into it,
             # fft_input_view), hence the kernel is centred on the origin: taps -p..p wrap around to S-p..S-1
             wp = torch.zeros(tuple(w0.shape[:2]) + S, dtype=torch.float32, device=w0.device)
@@ -395,6 +405,17 @@ class _FoldedV2V:
             # correlation (conj); the inverse transform's 1/N is folded in here, so irfftn runs unnormalised
             self.t[wkey] = (torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj() /
                             float(S[0] * S[1] * S[2])).contiguous()
+        if self._zdft_ok(x, w0, S):
+            # root grid: direct z-DFTs around dense 2-D complex transforms; the spectrum's slowest frequency index is kz,
+            # the weight spectrum is stored in the same order.  x is the unprojection's channels-last result.
+            zkey = ("Wz", S)
+            if zkey not in self.t:
+                self.t[zkey] = self.t[wkey].permute(0, 1, 4, 2, 3).contiguous()
+                if not any(k[0] == "xpad" for k in self.t if isinstance(k, tuple)):
+                    del self.t[wkey]                       # nobody asked for the planar buffer: keep one spectrum only
+            Xs = _lib.cfft2d_(_lib.zdft_fwd_cl(x, cin, S), False)
+            Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self.t[zkey]), True)
+            return _lib.zdft_inv_cl(Ys, X, Y, Z, S[2], s0, True)
         if getattr(x, "_sp3d_fft_shape", None) == S and x.shape[1] == cin and \
                 x.stride() == (x.stride(0), S[0] * S[1] * S[2], S[1] * S[2], S[2], 1):
             # x IS the signal corner of a zero-padded buffer (fft_input_view / fft_input_views): no pad/copy pass
@@ -473,6 +494,7 @@ class V2VNet(nn.Module):
         self.fused_inference = True      # eval + no_grad + GPU: BatchNorm-folded plan with fused epilogues
         self.fft_front = True            # ... whose 7x7x7 opening conv runs in the frequency domain (rocFFT)
         self.winograd = True             # ... and whose wide low-resolution 3x3x3 convs run as Winograd F(2,3)
+        self.zdft = True                 # ... root grid: direct z-DFTs + dense 2-D transforms instead of the 3-D real plans
         self._plan = None
         self.reset_parameters()
 
@@ -534,6 +556,19 @@ class V2VNet(nn.Module):
         whole = buf[:P, :, :X, :Y, :Z]
         chunks = [(n, _FoldedV2V.tag_fft_view(buf[a:a + m, :, :X, :Y, :Z], S)) for a, n, m in sizes]
         return whole, chunks
+
+    def wants_channels_last_cubes(self, X, Y, Z) -> bool:
+        """True when the next inference forward's opening conv reads channels-last 16-channel cubes directly (direct
+        z-DFT form, root grid): the caller should ask the unprojection for its channels-last result, not fill input_view"""
+        from . import _lib
+        if not (self.wants_planar_input() and getattr(self, "zdft", True) and self.front_layers[0].block[0].kernel_size == (7, 7, 7)):
+            return False
+        w0, w1 = self.front_layers[0].block[0].weight, self.front_layers[1].res_branch[0].weight
+        k = int(w0.shape[2])
+        S = _FoldedV2V._fft_shape(X, Y, Z, k)
+        cl = w1.is_contiguous(memory_format=torch.channels_last_3d) and not w1.is_contiguous()
+        return bool(w0.is_cuda and cl and (int(Z), int(S[2]), 16) in _lib.ZDFT_SHAPES and int(w0.shape[0]) == 16
+                    and int(w0.shape[1]) <= 16)
 
     def wants_planar_input(self) -> bool:
         """True when the next forward will take the FFT opening conv: it reads plain (B,C,X,Y,Z) cubes with the real

@@ -914,3 +914,39 @@ def test_upsample_scatter_with_output_head(J):
     got = _lib.upsample2x_head_(x, wg, shift, skip, wo, bo)
     assert got.shape == want.shape
     assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(2, 12, 20, 18, 26, 15), (1, 16, 7, 22, 8, 16)])
+def test_direct_z_dft_passes_equal_torch_fft(dims):
+    """sp3d_zdft_fwd_cl + sp3d_cfft2d == rfftn of the zero-padded planar volume (kz slowest), and
+    sp3d_cfft2d(inverse) + sp3d_zdft_inv_cl == relu(shift + irfftn(norm='forward'))[:X,:Y,:Z] in channels-last"""
+    from selfpose3d_amd import _lib
+    B, X, Y, SX, SY, cout = dims
+    Z, SZ, C = 20, 28, 16
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    pad = torch.zeros(B, cout, SX, SY, SZ, device="cuda")
+    pad[:, :, :X, :Y, :Z] = x[:, :cout]
+    ref = torch.fft.rfftn(pad, dim=(2, 3, 4)).permute(0, 1, 4, 2, 3).contiguous()
+    spec = _lib.zdft_fwd_cl(x, cout, (SX, SY, SZ))
+    zref = torch.fft.rfft(pad, dim=4).permute(0, 1, 4, 2, 3)
+    scale = float(torch.view_as_real(zref).abs().max())
+    assert float((torch.view_as_real(spec) - torch.view_as_real(zref)).abs().max()) <= 3e-6 * scale
+    _lib.cfft2d_(spec, False)
+    scale = float(torch.view_as_real(ref).abs().max())
+    assert float((torch.view_as_real(spec) - torch.view_as_real(ref)).abs().max()) <= 3e-6 * scale
+    # way back, 16 output channels: spectrum of a real (B,16,SX,SY,SZ) volume
+    vol = torch.randn(B, 16, SX, SY, SZ, generator=g).cuda()
+    sp = torch.fft.rfftn(vol, dim=(2, 3, 4))
+    shift = torch.randn(16, generator=g).cuda()
+    for relu in (True, False):
+        want = torch.fft.irfftn(sp, s=(SX, SY, SZ), dim=(2, 3, 4), norm="forward")[:, :, :X, :Y, :Z] + shift.view(1, 16, 1, 1, 1)
+        if relu:
+            want = torch.relu(want)
+        ks = sp.permute(0, 1, 4, 2, 3).contiguous()
+        got = _lib.zdft_inv_cl(_lib.cfft2d_(ks, True), X, Y, Z, SZ, shift, relu)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
+        assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max())
+    with pytest.raises(_lib.Sp3dError):
+        _lib.zdft_fwd_cl(x[..., :16].contiguous(memory_format=torch.channels_last_3d), cout, (SX, SY, 20))

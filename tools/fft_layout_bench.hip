@@ -59,5 +59,21 @@ int main()
         if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) printf("batch-innermost plan failed %d %d\n", r1, r2);
         else printf("batch-innermost   fwd %.1f us   inv %.1f us\n", time_exec(f, false, re, cx, 50, 1, 0, 0), time_exec(i, true, cx, re, 50, 1, 0, 0));
     }
+    {   // z transform done elsewhere: dense 2-D complex transforms over (x,y), one per (b,c,kz) / (b,o,kz)
+        hipfftHandle f;
+        int n2[2] = {SX, SY};
+        hipfftComplex *big; hipMalloc(&big, (size_t)B * 32 * SZc * SX * SY * 8); hipMemset(big, 0, (size_t)B * 32 * SZc * SX * SY * 8);
+        for (int batch : {B * C * SZc, B * 32 * SZc}) {
+            hipfftPlanMany(&f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2C, batch);
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < 3; ++i) hipfftExecC2C(f, big, big, HIPFFT_FORWARD);
+            hipDeviceSynchronize(); hipEventRecord(e0);
+            for (int i = 0; i < 50; ++i) hipfftExecC2C(f, big, big, HIPFFT_FORWARD);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("2-D C2C 88x88 in place, batch %d: %.1f us\n", batch, ms * 1000.f / 50);
+            hipfftDestroy(f);
+        }
+    }
     return 0;
 }
