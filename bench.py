@@ -149,8 +149,9 @@ def event_time_ms(fn, iters, dev):
 
 
 def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
-    """The dominant kernel of the unprojection as THIS step runs it (planar cubes for the frequency-domain opening
-    conv -> the 64-consecutive-voxel pipelined kernel), timed alone with HIP events on the launch stream; next to it the
+    """The dominant kernel of the unprojection as THIS step runs it (channels-last 16-channel cubes for the opening conv's
+    z-DFT pass -> the 4x4x4-brick kernel; planar cubes -> the 64-consecutive-voxel pipelined kernel otherwise), timed
+    alone with HIP events on the launch stream; next to it the
     path time (re-tiling pass included when the heat-maps arrive planar), the same kernel on inputs that rotate through
     8 x 39 MB (MALL-cold-ish), and the other unprojection kernels of the library on the same workload."""
     from selfpose3d_amd import _lib
@@ -167,10 +168,13 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     packed = src if src is not None else _lib.pack_heatmaps(planar, jp=16)
     views = [packed[c] for c in range(V)]
 
-    def k_step_kernel():          # what the bench step launches: planar result, library default for this grid
+    # what the bench step launches: on this grid the opening conv's z pass reads channels-last 16-channel cubes, so the
+    # step runs the 4x4x4-brick kernel (library default for channels-last results); a V2V that wants planar cubes gets
+    # the 64-consecutive-voxel kernel
+    def k_lin_planar():           # planar result, library default for this grid: 64 consecutive voxels per wave
         _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False)
 
-    def k_brick_cl():             # channels-last result (V2V without the FFT front): 4x4x4-brick kernel
+    def k_brick_cl():             # channels-last result: 4x4x4-brick kernel
         _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
                            channels_last=True)
 
@@ -188,8 +192,11 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     def k_pack():
         _lib.pack_heatmaps(planar, jp=16, out=scratch)
 
-    t_k = event_time_ms(k_step_kernel, iters, dev)
+    with torch.no_grad():
+        step_cl = bool(getattr(model.v2v_net, "wants_channels_last_cubes", lambda *a: False)(*cube))
+    t_lin = event_time_ms(k_lin_planar, iters, dev)
     t_brick = event_time_ms(k_brick_cl, iters, dev)
+    t_k = t_brick if step_cl else t_lin
     t_planar = event_time_ms(k_planar, max(10, iters // 10), dev)
     t_pack = event_time_ms(k_pack, iters, dev)
     with torch.no_grad():
@@ -202,7 +209,10 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "sp3d::unproject_pipe_kernel<16,true,1,false,float,float>", "kernel_us": round(t_k * 1e3, 2),
+        "kernel": "sp3d::unproject_brick_kernel<16,true,float,float>" if step_cl
+                  else "sp3d::unproject_pipe_kernel<16,true,1,false,float,float>", "kernel_us": round(t_k * 1e3, 2),
+        "kernel_result": "channels-last (B,80,80,20,16) cubes read by the opening conv's z-DFT pass" if step_cl
+                         else "planar (B,15,80,80,20) cubes",
         "algorithmic_bytes": int(alg_bytes),
         "path_us": round(path * 1e3, 2),
         "path": "unprojection kernel only: the heat-maps arrive as views of the backbone's channels-last buffer"
@@ -211,15 +221,19 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
         "path_us_planar_handover": round((t_k + t_pack) * 1e3, 2),
         "kernel_us_strided_result": None if t_strided is None else round(t_strided * 1e3, 2),
         "other_kernels_us": {"pack_nhwc_kernel<16>": round(t_pack * 1e3, 2),
-                             "unproject_brick_kernel<16,true> (channels-last result)": round(t_brick * 1e3, 2),
+                             ("unproject_pipe_kernel<16,true,1> (planar result)" if step_cl else
+                              "unproject_brick_kernel<16,true> (channels-last result)"):
+                                 round((t_lin if step_cl else t_brick) * 1e3, 2),
                              "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},
         "timing": f"HIP events on the launch stream, {iters} back-to-back launches, inputs L2/MALL-warm",
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # PMC record of the kernel the step runs (tools/profile_round.sh): the brick kernel's or the planar-result kernel's
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json" if step_cl else "pmc_traffic_planar.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("workload") == f"B{B}_V{V}_J{J}_{w}x{h}_{cube[0]}x{cube[1]}x{cube[2]}":
+            if rec.get("workload") == f"B{B}_V{V}_J{J}_{w}x{h}_{cube[0]}x{cube[1]}x{cube[2]}" and \
+                    ("brick" in rec.get("kernel", "")) == step_cl:
                 out["traffic"] = rec.get("hbm_bytes_per_launch")
                 out["traffic_source"] = rec.get("source")
         except Exception:
@@ -232,8 +246,8 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
         def k_cold():
             p = sets[state["i"] % nset]
             state["i"] += 1
-            _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube,
-                               gs, img, False)
+            _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16 if step_cl else J,
+                               h, w, cube, gs, img, False, channels_last=step_cl)
         t_cold = event_time_ms(k_cold, iters, dev)
         out["kernel_us_rotating_inputs"] = round(t_cold * 1e3, 2)
         out["frac_rotating_inputs"] = round(alg_bytes / (t_cold * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

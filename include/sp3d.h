@@ -244,6 +244,11 @@ int sp3d_irfft3d(float *in, float *out, int batch, int SX, int SY, int SZ, void 
 /* In-place batched 2-D complex transform of dense (batch,SX,SY) planes of interleaved (re,im) floats, unnormalised;
  * inverse != 0: e^{+i} kernel.  Cached hipFFT plan per (device, batch, SX, SY). */
 int sp3d_cfft2d(float *data, int batch, int SX, int SY, int inverse, void *stream);
+/* The same with the caller's zero-padding knowledge: only the first rows_in rows (index along SX) of every input plane are
+ * non-zero and only the first rows_out rows of every result plane are needed (the others may be left unwritten / stale).
+ * 88 x 88 planes run as ONE kernel with the plane in LDS (one HBM round trip instead of the plan's two strided passes);
+ * other sizes use the hipFFT plan on whole planes. */
+int sp3d_cfft2d_ex(float *data, int batch, int SX, int SY, int inverse, int rows_in, int rows_out, void *stream);
 
 /* z passes of the ROOT GRID's opening conv (v2v_net.py:113-117 on the 80x80x20 grid) as direct DFTs, spectrum layout
  * (B, channels, SZ/2+1, SX, SY) so that the x,y passes are sp3d_cfft2d over batch = B*channels*(SZ/2+1) planes:

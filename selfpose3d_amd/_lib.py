@@ -27,7 +27,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
@@ -364,17 +364,26 @@ def irfft3d_(spec: torch.Tensor, SZ: int) -> torch.Tensor:
 ZDFT_SHAPES = {(20, 28, 16)}       # (Z, SZ, channels) the direct z-DFT kernels are built for
 
 
-def cfft2d_(spec: torch.Tensor, inverse: bool) -> torch.Tensor:
-    """in-place unnormalised 2-D complex FFT over the last two dims of a dense complex64 tensor"""
+def cfft2d_(spec: torch.Tensor, inverse: bool, rows_in: Optional[int] = None, rows_out: Optional[int] = None,
+             library: bool = False) -> torch.Tensor:
+    """in-place unnormalised 2-D complex FFT over the last two dims of a dense complex64 tensor.  rows_in: only the first
+    rows_in rows of each input plane are non-zero; rows_out: only the first rows_out rows of each result are needed (the
+    rest is unspecified).  library=True forces the hipFFT plan (whole planes)."""
     lib = load()
     _require_cuda(spec, "spec")
     if not spec.is_contiguous() or spec.dtype != torch.complex64 or spec.dim() < 2:
         raise Sp3dError("cfft2d_: dense complex64 tensor with >= 2 dims expected")
     lib.sp3d_cfft2d.restype = C.c_int
     lib.sp3d_cfft2d.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    lib.sp3d_cfft2d_ex.restype = C.c_int
+    lib.sp3d_cfft2d_ex.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
     SX, SY = int(spec.shape[-2]), int(spec.shape[-1])
-    check(lib.sp3d_cfft2d(spec.data_ptr(), int(spec.numel() // (SX * SY)), SX, SY, 1 if inverse else 0,
-                          _stream(spec.device)), "sp3d_cfft2d")
+    batch = int(spec.numel() // (SX * SY))
+    if library:
+        check(lib.sp3d_cfft2d(spec.data_ptr(), batch, SX, SY, 1 if inverse else 0, _stream(spec.device)), "sp3d_cfft2d")
+    else:
+        check(lib.sp3d_cfft2d_ex(spec.data_ptr(), batch, SX, SY, 1 if inverse else 0, SX if rows_in is None else int(rows_in),
+                                 SX if rows_out is None else int(rows_out), _stream(spec.device)), "sp3d_cfft2d_ex")
     return spec
 
 

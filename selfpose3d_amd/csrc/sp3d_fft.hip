@@ -123,36 +123,37 @@ template <int SZ> struct Twiddles {
 constexpr int ZD_TY = 16;                                 // y rows per workgroup
 template <int Z, int C> constexpr int zd_pitch() { return Z * C + 4; }
 
-// x (B,X,Y,Z,C) dense channels-last real -> out (B,Cout,SZ/2+1,SX,SY) complex, Cout <= C channels kept
+// x (B,X,Y,Z,C) dense channels-last real -> out (B,Cout,SZ/2+1,SX,SY) complex, Cout <= C channels kept.
+// A workgroup owns 16 consecutive positions p = x*SY + y of one sample's (padded) x,y plane - whatever row they fall in -
+// so that each of its stores is one whole, aligned 128-byte line of a (c,kz) plane (16 complex values); with tiles cut per
+// row every other row's lines were written in two halves by different workgroups (SY*8 B = 5.5 lines): 26 -> 17 us.
 template <int Z, int SZ, int C>
 __global__ __launch_bounds__(256) void zdft_fwd_cl_kernel(const float *__restrict__ x, float2 *__restrict__ out, int X, int Y,
                                                          int SX, int SY, int Cout)
 {
-    static_assert(C == 16 && (Z * C) % 4 == 0, "16 channels x 16 rows = 256 threads");
+    static_assert(C == 16 && (Z * C) % 4 == 0, "16 channels x 16 positions = 256 threads");
     constexpr int K = SZ / 2 + 1, P = zd_pitch<Z, C>();
     constexpr Twiddles<SZ> tw{};
     __shared__ __attribute__((aligned(16))) float tile[ZD_TY * P];
-    const int nyt = (SY + ZD_TY - 1) / ZD_TY;
-    int r = blockIdx.x;
-    const int yt = r % nyt; r /= nyt;
-    const int xx = r % SX;
-    const int b = r / SX;
-    const int y0 = yt * ZD_TY;
+    const int plane = SX * SY;
+    const int ntile = (plane + ZD_TY - 1) / ZD_TY;
+    const int b = blockIdx.x / ntile;
+    const int p0 = (blockIdx.x - b * ntile) * ZD_TY;
     const int t = threadIdx.x, yy = t & 15, c = ((t >> 6) << 2) + ((t >> 4) & 3);
-    const int ny = (xx < X) ? max(0, min(ZD_TY, Y - y0)) : 0;          // rows of this tile that carry signal
-    if (ny > 0) {
-        const float4 *src = reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + xx) * Y + y0) * Z) * C);
-        constexpr int R4 = Z * C / 4;
-        for (int i = t; i < ny * R4; i += 256) {
-            const int row = i / R4, rem = i - row * R4;
-            *reinterpret_cast<float4 *>(tile + row * P + 4 * rem) = src[i];
-        }
+    constexpr int R4 = Z * C / 4;
+    for (int i = t; i < ZD_TY * R4; i += 256) {
+        const int row = i / R4, rem = i - row * R4;
+        const int p = p0 + row, px = p / SY, py = p - px * SY;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (px < X && py < Y) v = reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + px) * Y + py) * Z) * C)[rem];
+        *reinterpret_cast<float4 *>(tile + row * P + 4 * rem) = v;
     }
     __syncthreads();
+    const int p = p0 + yy, px = p / SY, py = p - px * SY;
     float re[K], im[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { re[k] = 0.0f; im[k] = 0.0f; }
-    if (yy < ny && c < Cout) {
+    if (px < X && py < Y && c < Cout) {
         float v[Z];
 #pragma unroll
         for (int z = 0; z < Z; ++z) v[z] = tile[yy * P + z * C + c];
@@ -166,10 +167,10 @@ __global__ __launch_bounds__(256) void zdft_fwd_cl_kernel(const float *__restric
             }
         }
     }
-    if (c < Cout && y0 + yy < SY) {
-        float2 *o = out + ((((int64_t)b * Cout + c) * K) * SX + xx) * SY + y0 + yy;
+    if (c < Cout && p < plane) {
+        float2 *o = out + (((int64_t)b * Cout + c) * K) * plane + p;
 #pragma unroll
-        for (int k = 0; k < K; ++k) o[(int64_t)k * SX * SY] = make_float2(re[k], im[k]);
+        for (int k = 0; k < K; ++k) o[(int64_t)k * plane] = make_float2(re[k], im[k]);
     }
 }
 
@@ -223,6 +224,135 @@ __global__ __launch_bounds__(256) void zdft_inv_cl_kernel(const float2 *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 88 x 88 complex plane transform in ONE kernel (the x,y passes of the root grid's opening conv): a workgroup keeps a
+// whole plane (62 KB) in LDS, so the plane crosses HBM once each way - the library's plan runs two strided out-of-place
+// passes (2 x 32 us for 960 planes).  88 = 11 x 8, Cooley-Tukey: n = 8 n1 + n2, k = k1 + 11 k2:
+//   A: for every n2 an 11-point DFT over n1 (symmetric form: 100 real FMAs), times W88^(n2 k1), stored at 8 k1 + n2;
+//   B: for every k1 an 8-point DFT over n2 (radix 2), stored at k1 + 11 k2 (all reads of B before any of its writes).
+// Row pass then column pass; in both the 64 lanes of a wave work on different lines (rows: LDS stride 89 complex -
+// conflict-free for 8-byte accesses; columns: consecutive addresses).  inverse: conj in, conj out.  Unnormalised.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int F88 = 88, F88_PITCH = 89, F88_NT = 512;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+
+template <bool COLS> __device__ __forceinline__ int f88_at(int line, int pos) { return COLS ? pos * F88_PITCH + line : line * F88_PITCH + pos; }
+
+template <bool COLS>
+__device__ __forceinline__ void f88_pass(float2 *pl, const float2 *tws, int tid, int nlines)
+{
+    constexpr Twiddles<11> t11{};
+    // only lines < nlines are transformed (row pass: the others are all-zero inputs or outputs nobody reads)
+    // A: tasks (line, n2)
+    for (int task = tid; task < nlines * 8; task += F88_NT) {
+        const int line = task % nlines, n2 = task / nlines;
+        float2 a[11];
+#pragma unroll
+        for (int n1 = 0; n1 < 11; ++n1) a[n1] = pl[f88_at<COLS>(line, 8 * n1 + n2)];
+        float2 sm[5], df[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { sm[j] = cadd(a[j + 1], a[10 - j]); df[j] = csub(a[j + 1], a[10 - j]); }
+        float2 out[11];
+        out[0] = a[0];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) out[0] = cadd(out[0], sm[j]);
+#pragma unroll
+        for (int k = 1; k <= 5; ++k) {
+            float2 cpart = a[0], spart = make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 1; j <= 5; ++j) {
+                const int m = (j * k) % 11;
+                cpart.x = fmaf(sm[j - 1].x, t11.c[m], cpart.x); cpart.y = fmaf(sm[j - 1].y, t11.c[m], cpart.y);
+                spart.x = fmaf(df[j - 1].x, t11.s[m], spart.x); spart.y = fmaf(df[j - 1].y, t11.s[m], spart.y);
+            }
+            // X_k = C - i S,  X_{11-k} = C + i S
+            out[k] = make_float2(cpart.x + spart.y, cpart.y - spart.x);
+            out[11 - k] = make_float2(cpart.x - spart.y, cpart.y + spart.x);
+        }
+        pl[f88_at<COLS>(line, n2)] = out[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 11; ++k1)
+            pl[f88_at<COLS>(line, 8 * k1 + n2)] = n2 == 0 ? out[k1] : cmul(out[k1], tws[n2 * k1]);
+    }
+    __syncthreads();
+    // B: tasks (line, k1); two tasks per thread at most (88 * 11 = 968 <= 2 * 512)
+    float2 b[2][8];
+    const float r = 0.70710678118654752440f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int task = tid + u * F88_NT;
+        if (task < nlines * 11) {
+            const int line = task % nlines, k1 = task / nlines;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) b[u][n2] = pl[f88_at<COLS>(line, 8 * k1 + n2)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int task = tid + u * F88_NT;
+        if (task < nlines * 11) {
+            const int line = task % nlines, k1 = task / nlines;
+            const float2 *q = b[u];
+            const float2 u0 = cadd(q[0], q[4]), u1 = csub(q[0], q[4]), u2 = cadd(q[2], q[6]), u3 = mul_mi(csub(q[2], q[6]));
+            const float2 u4 = cadd(q[1], q[5]), u5 = csub(q[1], q[5]), u6 = cadd(q[3], q[7]), u7 = mul_mi(csub(q[3], q[7]));
+            const float2 v0 = cadd(u0, u2), v2 = csub(u0, u2), v1 = cadd(u1, u3), v3 = csub(u1, u3);
+            const float2 v4 = cadd(u4, u6), v6 = csub(u4, u6), v5 = cadd(u5, u7), v7 = csub(u5, u7);
+            const float2 w5 = make_float2(r * (v5.x + v5.y), r * (v5.y - v5.x));        // v5 * (1 - i)/sqrt2
+            const float2 w6 = mul_mi(v6);
+            const float2 w7 = make_float2(r * (v7.y - v7.x), -r * (v7.x + v7.y));       // v7 * (-1 - i)/sqrt2
+            pl[f88_at<COLS>(line, k1)] = cadd(v0, v4);
+            pl[f88_at<COLS>(line, k1 + 11)] = cadd(v1, w5);
+            pl[f88_at<COLS>(line, k1 + 22)] = cadd(v2, w6);
+            pl[f88_at<COLS>(line, k1 + 33)] = cadd(v3, w7);
+            pl[f88_at<COLS>(line, k1 + 44)] = csub(v0, v4);
+            pl[f88_at<COLS>(line, k1 + 55)] = csub(v1, w5);
+            pl[f88_at<COLS>(line, k1 + 66)] = csub(v2, w6);
+            pl[f88_at<COLS>(line, k1 + 77)] = csub(v3, w7);
+        }
+    }
+    __syncthreads();
+}
+
+// rows_in: only the first rows_in rows of every input plane are non-zero (forward transform of zero-padded data; the
+// others are not even read); rows_out: only the first rows_out rows of the result are needed (the others are not written)
+__global__ __launch_bounds__(F88_NT) void cfft2d_88_kernel(float2 *__restrict__ data, int inverse, int rows_in, int rows_out)
+{
+    extern __shared__ float2 lds88[];
+    float2 *pl = lds88, *tws = lds88 + F88 * F88_PITCH;
+    constexpr Twiddles<88> t88{};
+    const int tid = threadIdx.x;
+    float2 *base = data + (int64_t)blockIdx.x * F88 * F88;
+    if (tid < F88) tws[tid] = make_float2(t88.c[tid], -t88.s[tid]);
+    for (int i = tid; i < F88 * F88 / 2; i += F88_NT) {
+        const int e = 2 * i, rr = e / F88, cc = e - rr * F88;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (rr < rows_in) v = reinterpret_cast<const float4 *>(base)[i];
+        if (inverse) { v.y = -v.y; v.w = -v.w; }
+        pl[rr * F88_PITCH + cc] = make_float2(v.x, v.y);
+        pl[rr * F88_PITCH + cc + 1] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    if (rows_out < F88) {                           // way back: along x first, then along y for the rows that are read
+        f88_pass<true>(pl, tws, tid, F88);
+        f88_pass<false>(pl, tws, tid, rows_out);
+    } else {                                        // way in: along y for the rows that carry signal, then along x
+        f88_pass<false>(pl, tws, tid, rows_in);
+        f88_pass<true>(pl, tws, tid, F88);
+    }
+    for (int i = tid; i < rows_out * F88 / 2; i += F88_NT) {
+        const int e = 2 * i, rr = e / F88, cc = e - rr * F88;
+        const float2 p0 = pl[rr * F88_PITCH + cc], p1 = pl[rr * F88_PITCH + cc + 1];
+        float4 v = make_float4(p0.x, p0.y, p1.x, p1.y);
+        if (inverse) { v.y = -v.y; v.w = -v.w; }
+        reinterpret_cast<float4 *>(base)[i] = v;
+    }
+}
 } // namespace sp3d
 
 extern "C" int sp3d_zdft_fwd_cl(const float *x, float *spec, int B, int C, int Cout, int X, int Y, int Z, int SX, int SY, int SZ,
@@ -231,7 +361,7 @@ extern "C" int sp3d_zdft_fwd_cl(const float *x, float *spec, int B, int C, int C
     if (B <= 0 || C <= 0 || Cout <= 0 || Cout > C || X <= 0 || Y <= 0 || Z <= 0 || SX < X || SY < Y || SZ < Z) return SP3D_EINVAL;
     if (!x || !spec) return SP3D_ENULL;
     if (!(C == 16 && Z == 20 && SZ == 28) || (reinterpret_cast<uintptr_t>(x) & 15)) return SP3D_EUNSUPPORTED;
-    const int64_t blocks = (int64_t)B * SX * ((SY + sp3d::ZD_TY - 1) / sp3d::ZD_TY);
+    const int64_t blocks = (int64_t)B * (((int64_t)SX * SY + sp3d::ZD_TY - 1) / sp3d::ZD_TY);
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
     hipLaunchKernelGGL((sp3d::zdft_fwd_cl_kernel<20, 28, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<float2 *>(spec), X, Y, SX, SY, Cout);
@@ -249,6 +379,29 @@ extern "C" int sp3d_zdft_inv_cl(const float *spec, float *y, const float *shift,
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
     hipLaunchKernelGGL((sp3d::zdft_inv_cl_kernel<20, 28, 16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float2 *>(spec), y, shift, X, Y, SX, SY, relu);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+// sp3d_cfft2d with the zero-padding knowledge of its caller: only the first rows_in rows (x) of every input plane are
+// non-zero, only the first rows_out rows of every output plane are needed.  88 x 88 planes run in the single-kernel LDS
+// transform above; other sizes fall back to the hipFFT plan (full planes).
+extern "C" int sp3d_cfft2d_ex(float *data, int batch, int SX, int SY, int inverse, int rows_in, int rows_out, void *stream)
+{
+    if (batch <= 0 || SX <= 0 || SY <= 0 || rows_in <= 0 || rows_out <= 0 || rows_in > SX || rows_out > SX) return SP3D_EINVAL;
+    if (!data) return SP3D_ENULL;
+    if (SX != sp3d::F88 || SY != sp3d::F88 || (reinterpret_cast<uintptr_t>(data) & 15))
+        return sp3d_cfft2d(data, batch, SX, SY, inverse, stream);
+    const size_t lds = (size_t)(sp3d::F88 * sp3d::F88_PITCH + sp3d::F88) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(sp3d::cfft2d_88_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return (int)ea;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sp3d::cfft2d_88_kernel, dim3((unsigned)batch), dim3(sp3d::F88_NT), lds, (hipStream_t)stream,
+                       reinterpret_cast<float2 *>(data), inverse, rows_in, rows_out);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

@@ -413,8 +413,8 @@ class _FoldedV2V:
                 self.t[zkey] = self.t[wkey].permute(0, 1, 4, 2, 3).contiguous()
                 if not any(k[0] == "xpad" for k in self.t if isinstance(k, tuple)):
                     del self.t[wkey]                       # nobody asked for the planar buffer: keep one spectrum only
-            Xs = _lib.cfft2d_(_lib.zdft_fwd_cl(x, cin, S), False)
-            Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self.t[zkey]), True)
+            Xs = _lib.cfft2d_(_lib.zdft_fwd_cl(x, cin, S), False, rows_in=X)          # rows x >= X are zero padding
+            Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self.t[zkey]), True, rows_out=X)   # ... and not read on the way back
             return _lib.zdft_inv_cl(Ys, X, Y, Z, S[2], s0, True)
         if getattr(x, "_sp3d_fft_shape", None) == S and x.shape[1] == cin and \
                 x.stride() == (x.stride(0), S[0] * S[1] * S[2], S[1] * S[2], S[2], 1):

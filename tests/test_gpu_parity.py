@@ -950,3 +950,37 @@ def test_direct_z_dft_passes_equal_torch_fft(dims):
         assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max())
     with pytest.raises(_lib.Sp3dError):
         _lib.zdft_fwd_cl(x[..., :16].contiguous(memory_format=torch.channels_last_3d), cout, (SX, SY, 20))
+
+
+@pytest.mark.gpu
+def test_single_kernel_88x88_plane_transform_equals_torch_fft():
+    """sp3d_cfft2d_ex on 88x88 planes (one kernel, plane in LDS) == torch.fft.fft2 / unnormalised ifft2, == the hipFFT
+    plan; rows_in / rows_out only skip work on rows that are zero / unread"""
+    from selfpose3d_amd import _lib
+    g = torch.Generator().manual_seed(8)
+    z = torch.view_as_complex(torch.randn(7, 3, 88, 88, 2, generator=g)).cuda()
+    ref = torch.fft.fft2(z)
+    scale = float(torch.view_as_real(ref).abs().max())
+    got = _lib.cfft2d_(z.clone(), False)
+    assert float(torch.view_as_real(got - ref).abs().max()) <= 3e-6 * scale
+    lib_plan = _lib.cfft2d_(z.clone(), False, library=True)
+    assert float(torch.view_as_real(got - lib_plan).abs().max()) <= 3e-6 * scale
+    back = _lib.cfft2d_(ref.clone(), True)
+    assert float(torch.view_as_real(back / (88 * 88) - z).abs().max()) <= 1e-5
+    want = torch.fft.ifft2(ref, norm="forward")
+    assert float(torch.view_as_real(back - want).abs().max()) <= 3e-6 * float(torch.view_as_real(want).abs().max())
+    # zero-padded input: rows >= 80 are zero and declared so
+    zp = z.clone()
+    zp[..., 80:, :] = 0
+    got = _lib.cfft2d_(zp.clone(), False, rows_in=80)
+    ref = torch.fft.fft2(zp)
+    assert float(torch.view_as_real(got - ref).abs().max()) <= 3e-6 * float(torch.view_as_real(ref).abs().max())
+    # only the first 80 rows of the inverse are needed
+    part = _lib.cfft2d_(ref.clone(), True, rows_out=80)
+    want = torch.fft.ifft2(ref, norm="forward")
+    assert float(torch.view_as_real(part[..., :80, :] - want[..., :80, :]).abs().max()) <= \
+        3e-6 * float(torch.view_as_real(want).abs().max())
+    # other plane sizes go through the library plan
+    y = torch.view_as_complex(torch.randn(5, 30, 18, 2, generator=g)).cuda()
+    got = _lib.cfft2d_(y.clone(), False, rows_in=20)
+    assert float(torch.view_as_real(got - torch.fft.fft2(y)).abs().max()) <= 3e-6 * float(torch.view_as_real(torch.fft.fft2(y)).abs().max())

@@ -75,5 +75,20 @@ int main()
             hipfftDestroy(f);
         }
     }
+    {   // which padded x,y length is cheapest for the dense 2-D plan (>= 86 needed)?
+        hipfftComplex *big; hipMalloc(&big, (size_t)960 * 128 * 128 * 8); hipMemset(big, 0, (size_t)960 * 128 * 128 * 8);
+        for (int L : {86, 88, 90, 96, 98, 100, 104, 108, 112, 120, 128}) {
+            hipfftHandle f; int n2[2] = {L, L};
+            if (hipfftPlanMany(&f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2C, 960) != HIPFFT_SUCCESS) { printf("plan %d failed\n", L); continue; }
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < 3; ++i) hipfftExecC2C(f, big, big, HIPFFT_FORWARD);
+            hipDeviceSynchronize(); hipEventRecord(e0);
+            for (int i = 0; i < 50; ++i) hipfftExecC2C(f, big, big, HIPFFT_FORWARD);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("2-D C2C %dx%d batch 960: %.1f us  (%.2f ns per point)\n", L, L, ms * 1000.f / 50, ms * 1e6f / 50 / (960.0f * L * L));
+            hipfftDestroy(f);
+        }
+    }
     return 0;
 }

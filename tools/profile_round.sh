@@ -18,11 +18,14 @@ rm -rf $O/${TAG}_trace
 # 2. PMC: unprojection kernels on the bench workload (planar default), stress and fine configs
 cd $R
 bash tools/collect_pmc.sh $O/${TAG}_pmc_coarse_b4 coarse_b4_v5 -1 > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/${TAG}_pmc_coarse_b4_cl coarse_b4_v5 -1 --cl > /dev/null 2>&1
+python tools/pmc_traffic.py $O/${TAG}_pmc_coarse_b4/summary.json B4_V5_J15_240x128_80x80x20 > $O/pmc_traffic_planar.json
+python tools/pmc_traffic.py $O/${TAG}_pmc_coarse_b4_cl/summary.json B4_V5_J15_240x128_80x80x20 > $O/pmc_traffic.json
 bash tools/collect_pmc.sh $O/${TAG}_pmc_stress_v10 stress_b1_v10 -1 > /dev/null 2>&1
 bash tools/collect_pmc.sh $O/${TAG}_pmc_stress_v10_cl stress_b1_v10 -1 --cl > /dev/null 2>&1
 bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64 fine_b10_v5 -1 > /dev/null 2>&1
 bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64_v24 fine_b10_v5 24 > /dev/null 2>&1
-for d in coarse_b4 stress_v10 stress_v10_cl fine64 fine64_v24; do rm -rf $O/${TAG}_pmc_$d/pass*/; done
+for d in coarse_b4 coarse_b4_cl stress_v10 stress_v10_cl fine64 fine64_v24; do rm -rf $O/${TAG}_pmc_$d/pass*/; done
 # 3. PMC: fused Winograd kernel
 bash tools/pmc_wino_fused.sh > $O/${TAG}_pmc_wino_fused.txt 2>&1
 cp $O/pmc_wf/summary.json $O/${TAG}_pmc_wino_fused.json 2>/dev/null
