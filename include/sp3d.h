@@ -315,6 +315,14 @@ int sp3d_wino_output(const float *M, float *y, const float *shift, const float *
 int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode, int B,
                     int X, int Y, int Z, int C, int O, void *stream);
 
+/* sp3d_wino_fused with the products on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split exactly into
+ * three bf16 pieces (hi+mid+lo) and the six significant piece products are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 (dropped terms < 2^-24 relative).  U3: the pre-transformed weights of sp3d_wino_fused split on
+ * the host into 24-byte records [mid(4ch) hi(4ch) lo(4ch)] of bf16, record index ((p*(C/8) + chunk)*2 + half)*32 + o,
+ * channel = 8*chunk + 4*half + q (selfpose3d_amd/_lib.py: wino_weights_split).  Same arguments otherwise. */
+int sp3d_wino_fused_split(const float *x, const void *U3, float *y, const float *shift, const float *residual, int mode, int B,
+                          int X, int Y, int Z, int C, int O, void *stream);
+
 /*
  * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
  * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):

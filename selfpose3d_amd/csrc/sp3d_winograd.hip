@@ -357,6 +357,215 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same kernel with the products on the bf16 matrix pipe at fp32 accuracy.  v_mfma_f32_32x32x2_f32 runs at 1/16 of
+// the bf16 rate and (profiles/r02_pmc_wino_fused.json) keeps the matrix pipe 75 % busy at a throttled clock.
+// Every fp32 operand is split into three bf16 pieces a = hi + mid + lo (8+8+8 mantissa bits: exact), the six products
+// whose weight is >= 2^-16 relative - hh, hm, mh, hl, lh, mm - are formed exactly by v_mfma_f32_32x32x16_bf16
+// (bf16 x bf16 fits fp32) and accumulated in fp32; the dropped terms are < 2^-24 relative, i.e. below one fp32 ulp of
+// the product.  K = 16 of one MFMA = 4 channels x 2 (A piece, B piece) pairs per lane half:
+//     {hi,hi} x {bm,bh}   +   {mid,mid} x {bm,bh}   +   {lo,hi} x {bh,bl}
+// so 8 channels cost 3 MFMAs of 8 passes instead of 4 of 16: 2.7x fewer matrix cycles; the weights are split once on
+// the host (U3: per (point, chunk, lane half, output) one 24-byte record [bm(4ch) bh(4ch) bl(4ch)]).
+// ------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+struct WfB { u32x4 mh; u32x2 l; };              // [bm01 bm23 bh01 bh23] [bl01 bl23]
+
+template <int C, int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_fused3_kernel(const float *__restrict__ x, const unsigned *__restrict__ U3,
+                                                        float *__restrict__ y, const float *__restrict__ shift,
+                                                        const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
+                                                        int NBY, int NBZ)
+{
+    constexpr int O = 32, NCH = C / 8;
+    __shared__ __attribute__((aligned(16))) float region[WF_LDS];
+    const int lane = threadIdx.x, t = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int bz = bid % NBZ; bid /= NBZ;
+    const int by = bid % NBY; bid /= NBY;
+    const int bx = bid % NBX;
+    const int b = bid / NBX;
+    const int ttx = t & 3, tty = (t >> 2) & 3, ttz = t >> 4;
+    const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 4;
+    const float *rb = region + ((2 * ttz) * WF_RY + 2 * tty) * WF_ROW + (2 * ttx) * WF_VS + 4 * h;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][v] = 0.0f;
+
+#pragma unroll 1
+    for (int cc = 0; cc < NCH; ++cc) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i0 = 0; i0 < WF_RX * WF_RY * WF_RZ * 2; i0 += 64 * 5) {
+            float4 d[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = i0 + u * 64 + lane;
+                const int v = idx >> 1, half = idx & 1;
+                const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
+                const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
+                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx < WF_RX * WF_RY * WF_RZ * 2 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z)
+                    d[u] = *reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + cc * 8 + half * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int idx = i0 + u * 64 + lane;
+                if (idx < WF_RX * WF_RY * WF_RZ * 2) {
+                    const int v = idx >> 1, half = idx & 1;
+                    const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
+                    *reinterpret_cast<float4 *>(region + (vz * WF_RY + vy) * WF_ROW + vx * WF_VS + half * 4) = d[u];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // record of (point p = i*16 + jk, chunk cc, lane half h, output t): 6 dwords
+        const unsigned *ub = U3 + (((int64_t)cc * 2 + h) * 32 + t) * 6;
+        auto load_b = [&](int i, int jk) {
+            const unsigned *r = ub + (int64_t)(i * 16 + jk) * NCH * 2 * 32 * 6;
+            WfB w;
+            w.mh = *reinterpret_cast<const u32x4_a8 *>(r);
+            w.l = *reinterpret_cast<const u32x2_a8 *>(r + 4);
+            return w;
+        };
+        // B of x points 0,1 arrives one step ahead; B of x points 2,3 is fetched at the top of its own step (it is
+        // needed ~600 cycles later): 36 registers of weights in flight instead of 48
+        auto step = [&](int jk, int jk_next, const WfB (&bcur)[2], WfB (&bnxt)[2]) {
+            const int j = jk >> 2, k = jk & 3;
+            const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
+            const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
+            const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
+            const float *r00 = rb + (za * WF_RY + ya) * WF_ROW, *r10 = rb + (za * WF_RY + yb) * WF_ROW;
+            const float *r01 = rb + (zb * WF_RY + ya) * WF_ROW, *r11 = rb + (zb * WF_RY + yb) * WF_ROW;
+            WfB blate[2];
+            blate[0] = load_b(2, jk);
+            blate[1] = load_b(3, jk);
+            float g[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * WF_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * WF_VS);
+                const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * WF_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * WF_VS);
+                g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
+                g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
+                g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
+                g[xi][3] = fmaf(sz, fmaf(sy, v11.w, v01.w), fmaf(sy, v10.w, v00.w));
+            }
+            float cyz[4];
+#pragma unroll
+            for (int bc = 0; bc < 4; ++bc) {
+                const int bb = bc >> 1, c2 = bc & 1;
+                const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
+                const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
+                cyz[bc] = cy * cz;
+            }
+            f32x16 M0, M1;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { M0[v] = 0.0f; M1[v] = 0.0f; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // x transform: d0-d2, d1+d2, d2-d1, d1-d3; point 3 enters M1 with a minus sign: negate it here
+                float av[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    av[kk] = (i == 1) ? g[1][kk] + g[2][kk] : ((i == 3) ? g[3][kk] - g[1][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk]);
+                // a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits)
+                const unsigned hi01 = pack_bf16(av[0], av[1]), hi23 = pack_bf16(av[2], av[3]);
+                const float r0 = av[0] - bf16_lo(hi01), r1 = av[1] - bf16_hi(hi01), r2 = av[2] - bf16_lo(hi23), r3 = av[3] - bf16_hi(hi23);
+                const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
+                const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
+                const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+                const u32x4 Qhh = {hi01, hi23, hi01, hi23}, Qmm = {mid01, mid23, mid01, mid23}, Qlh = {lo01, lo23, hi01, hi23};
+                const WfB &w = (i < 2) ? bcur[i] : blate[i - 2];
+                const u32x4 Bmh = w.mh;
+                const u32x4 Bhl = {w.mh.z, w.mh.w, w.l.x, w.l.y};
+                if (i < 3) {
+                    M0 = mfma_bf16(Qhh, Bmh, M0);
+                    M0 = mfma_bf16(Qmm, Bmh, M0);
+                    M0 = mfma_bf16(Qlh, Bhl, M0);
+                }
+                if (i == 1 || i == 3) {
+                    M1 = mfma_bf16(Qhh, Bmh, M1);
+                    M1 = mfma_bf16(Qmm, Bmh, M1);
+                    M1 = mfma_bf16(Qlh, Bhl, M1);
+                }
+                if (i == 2) {                                      // M1 -= A.B: flip the sign bits of the weights
+                    const u32x4 nmh = Bmh ^ 0x80008000u, nhl = Bhl ^ 0x80008000u;
+                    M1 = mfma_bf16(Qhh, nmh, M1);
+                    M1 = mfma_bf16(Qmm, nmh, M1);
+                    M1 = mfma_bf16(Qlh, nhl, M1);
+                }
+                if (i == 1) {                                      // next step's early weights, mid-step
+                    bnxt[0] = load_b(0, jk_next);
+                    bnxt[1] = load_b(1, jk_next);
+                }
+            }
+#pragma unroll
+            for (int bc = 0; bc < 4; ++bc) {
+                const float coef = cyz[bc];
+                if (coef != 0.0f) {
+                    f32x16 cv;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) cv[v] = coef;
+                    acc[bc] = __builtin_elementwise_fma(M0, cv, acc[bc]);
+                    acc[4 + bc] = __builtin_elementwise_fma(M1, cv, acc[4 + bc]);
+                }
+            }
+        };
+        WfB b0[2], b1[2];
+        b0[0] = load_b(0, 0);
+        b0[1] = load_b(1, 0);
+#pragma unroll 1
+        for (int jk = 0; jk < 16; jk += 2) {
+            step(jk, jk + 1, b0, b1);
+            step(jk + 1, (jk + 2) & 15, b1, b0);
+        }
+    }
+
+    const float sh = shift[t];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = 8 * (v >> 2) + (v & 3) + 4 * h;
+            const int rx = row & 3, ry = (row >> 2) & 3, rz = row >> 4;
+            const int xo = ox0 + 2 * rx + (a >> 2), yo = oy0 + 2 * ry + ((a >> 1) & 1), zo = oz0 + 2 * rz + (a & 1);
+            if (xo < X && yo < Y && zo < Z) {
+                const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t;
+                float val = acc[a][v] + sh;
+                if (MODE == 2) val += res[idx];
+                if (MODE >= 1) val = fmaxf(val, 0.0f);
+                if (MODE == 3) val += res[idx];
+                y[idx] = val;
+            }
+        }
+    }
+}
+
 } // namespace sp3d
 
 extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
@@ -389,4 +598,26 @@ extern "C" int sp3d_debug_wino_fused_timeline(void *dev_buffer)
     (void)dev_buffer;
     return SP3D_EUNSUPPORTED;
 #endif
+}
+
+extern "C" int sp3d_wino_fused_split(const float *x, const void *U3, float *y, const float *shift, const float *residual, int mode,
+                                     int B, int X, int Y, int Z, int C, int O, void *stream)
+{
+    using namespace sp3d;
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
+    if (!x || !U3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if (O != 32 || (C != 16 && C != 32) || (reinterpret_cast<uintptr_t>(U3) & 7)) return SP3D_EUNSUPPORTED;
+    const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 3) / 4;
+    const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
+    if (blocks > 0x7fffffff) return SP3D_ERANGE;
+    const dim3 grid((unsigned)blocks), block(64);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned *u3 = reinterpret_cast<const unsigned *>(U3);
+#define SP3D_WF(C_, M_) hipLaunchKernelGGL((wino_fused3_kernel<C_, M_>), grid, block, 0, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
+#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }
+    if (C == 16) { SP3D_WFM(16) } else { SP3D_WFM(32) }
+#undef SP3D_WFM
+#undef SP3D_WF
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
 }

@@ -226,6 +226,9 @@ class _FoldedV2V:
             wino = lambda w: w.is_cuda and (w.shape[1] >= 64 or (w.shape[0] == 32 and w.shape[1] in (16, 32)))
             u1 = _lib.wino_weights(w1) if wino(w1) else None
             u2 = _lib.wino_weights(w2) if wino(w2) else None
+            for u in (u1, u2):                 # layers of the fused kernel: weights split for the bf16 matrix pipe
+                if u is not None and u.shape[2] == 32 and u.shape[1] in (16, 32):
+                    u._sp3d_split = _lib.wino_weights_split(u)
             if len(blk.skip_con) > 0:
                 ws, ss = self._fold(blk.skip_con[0], blk.skip_con[1])
                 t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws, u1, u2)
@@ -260,7 +263,8 @@ class _FoldedV2V:
                 # full-resolution layers: the transformed tensor would be hundreds of MB, so everything (transforms,
                 # v_mfma_f32_32x32x2_f32 products, epilogue) happens in one kernel: 225 us instead of 345 us at
                 # (4,32,80,80,20), 0.99 instead of 1.34 ms for eight 64^3 pose cubes
-                return _lib.wino_fused_conv3d_(x, u, shift, mode, residual)
+                u3 = getattr(u, "_sp3d_split", None) if getattr(self.net, "wino_split", True) else None
+                return _lib.wino_fused_conv3d_(x, u, shift, mode, residual, u3)
         return _lib.channel_shift_act_(F.conv3d(x, w, None, 1, 1), shift, mode, residual)
 
     def _res(self, x, name):
@@ -495,6 +499,7 @@ class V2VNet(nn.Module):
         self.fft_front = True            # ... whose 7x7x7 opening conv runs in the frequency domain (rocFFT)
         self.winograd = True             # ... and whose wide low-resolution 3x3x3 convs run as Winograd F(2,3)
         self.zdft = True                 # ... root grid: direct z-DFTs + dense 2-D transforms instead of the 3-D real plans
+        self.wino_split = True           # ... fused Winograd layers: exact 3-piece bf16 splits on the bf16 matrix pipe
         self._plan = None
         self.reset_parameters()
 

@@ -984,3 +984,39 @@ def test_single_kernel_88x88_plane_transform_equals_torch_fft():
     y = torch.view_as_complex(torch.randn(5, 30, 18, 2, generator=g)).cuda()
     got = _lib.cfft2d_(y.clone(), False, rows_in=20)
     assert float(torch.view_as_real(got - torch.fft.fft2(y)).abs().max()) <= 3e-6 * float(torch.view_as_real(torch.fft.fft2(y)).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 32, (16, 12, 8), 1), (1, 16, (9, 7, 5), 2), (1, 32, (8, 8, 4), 3), (2, 16, (24, 8, 4), 0)])
+def test_winograd_fused_split_kernel_has_fp32_accuracy(shape):
+    """sp3d_wino_fused_split (three exact bf16 pieces per operand on v_mfma_f32_32x32x16_bf16, fp32 accumulation) against
+    a float64 conv: same tolerance as the fp32-MFMA kernel AND an error no larger than 1.5x that kernel's (+1e-7)"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, (X, Y, Z), mode = shape
+    O = 32
+    g = torch.Generator(device="cpu").manual_seed(19)
+    x = (torch.randn((B, C, X, Y, Z), generator=g) * 3.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((O, C, 3, 3, 3), generator=g) * 0.05).cuda()
+    shift = torch.randn((O,), generator=g).cuda()
+    res = torch.randn((B, O, X, Y, Z), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    U = _lib.wino_weights(w)
+    U3 = _lib.wino_weights_split(U)
+    # the three pieces reproduce the fp32 weights exactly
+    back = U3.float().sum(4).permute(0, 1, 2, 4, 3).reshape(64, C, O)
+    assert torch.equal(back, U)
+    ref = F.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, O, 1, 1, 1)
+    if mode == 2:
+        ref = ref + res.double()
+    if mode >= 1:
+        ref = ref.clamp_min(0)
+    if mode == 3:
+        ref = ref + res.double()
+    r = res if mode >= 2 else None
+    y32 = _lib.wino_fused_conv3d_(x, U, shift, mode, r)
+    y3 = _lib.wino_fused_conv3d_(x, U, shift, mode, r, U3)
+    e32 = float((y32.double() - ref).abs().max())
+    e3 = float((y3.double() - ref).abs().max())
+    assert y3.shape == ref.shape and y3.is_contiguous(memory_format=torch.channels_last_3d)
+    assert e3 <= 5e-5 * max(1.0, float(ref.abs().max()))
+    assert e3 <= 1.5 * e32 + 1e-7, (e3, e32)

@@ -1,0 +1,51 @@
+"""fused Winograd kernel: fp32 MFMA against the exact three-piece bf16 split, time and error vs float64 (bench shapes)"""
+import json
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from selfpose3d_amd import _lib  # noqa: E402
+
+
+def timeit(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return round(a.elapsed_time(b) * 1e3 / iters, 1)
+
+
+out = {}
+for name, (B, C, X, Y, Z, mode) in {"root_32_relu": (4, 32, 80, 80, 20, 1), "root_32_res": (4, 32, 80, 80, 20, 2),
+                                    "root_16_relu": (4, 16, 80, 80, 20, 1), "pose8_32_res": (8, 32, 64, 64, 64, 2)}.items():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(32, C, 3, 3, 3, generator=g) * 0.05).cuda()
+    shift = torch.randn(32, generator=g).cuda()
+    res = torch.randn(B, 32, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d) if mode >= 2 else None
+    U = _lib.wino_weights(w)
+    U3 = _lib.wino_weights_split(U)
+    r = {"fp32_mfma_us": timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res)),
+         "bf16x3_us": timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3))}
+    if B * X * Y * Z <= 600000:
+        ref = F.conv3d(x[:1].double(), w.double(), padding=1) + shift.double().view(1, 32, 1, 1, 1)
+        if mode == 2:
+            ref = (ref + res[:1].double())
+        ref = ref.clamp_min(0)
+        y32 = _lib.wino_fused_conv3d_(x, U, shift, mode, res)[:1].double()
+        y3 = _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3)[:1].double()
+        d = F.conv3d(x[:1], w, padding=1) + shift.view(1, 32, 1, 1, 1)
+        if mode == 2:
+            d = d + res[:1]
+        d = d.clamp_min(0).double()
+        r.update(max_err_fp32_mfma=float((y32 - ref).abs().max()), max_err_bf16x3=float((y3 - ref).abs().max()),
+                 max_err_direct_fp32_conv=float((d - ref).abs().max()), ref_max=float(ref.abs().max()))
+    out[name] = r
+print(json.dumps(out, indent=1))
