@@ -323,6 +323,12 @@ int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift
 int sp3d_wino_fused_split(const float *x, const void *U3, float *y, const float *shift, const float *residual, int mode, int B,
                           int X, int Y, int Z, int C, int O, void *stream);
 
+/* The same scheme for the half-resolution layers (C = 32 | 64 -> O = 64): blocks of 4x4x1 tiles x 64 outputs on
+ * v_mfma_f32_16x16x32_bf16, 16-channel chunks.  U3 records [mid(4ch) hi(4ch) lo(4ch)] at index
+ * ((p*(C/16) + chunk)*4 + group)*64 + o, channel = 16*chunk + 4*group + q (_lib.wino_weights_split(U, 16)). */
+int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const float *shift, const float *residual, int mode,
+                            int B, int X, int Y, int Z, int C, int O, void *stream);
+
 /*
  * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
  * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):

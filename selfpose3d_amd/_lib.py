@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -582,17 +582,18 @@ def wino_weights(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(64, w.shape[1], w.shape[0]).float().contiguous()
 
 
-def wino_weights_split(U: torch.Tensor) -> torch.Tensor:
-    """U (64,C,O) fp32 -> the bf16 three-piece records sp3d_wino_fused_split reads: (64, C/8, 2, O, 3, 4) bfloat16 with
-    pieces ordered (mid, hi, lo) and channel = 8*chunk + 4*half + q; hi + mid + lo == U exactly (24 mantissa bits)"""
+def wino_weights_split(U: torch.Tensor, chunk: int = 8) -> torch.Tensor:
+    """U (64,C,O) fp32 -> the bf16 three-piece records the split kernels read: (64, C/chunk, chunk/4, O, 3, 4) bfloat16
+    with pieces ordered (mid, hi, lo) and channel = chunk*c + 4*group + q; hi + mid + lo == U exactly (24 mantissa bits).
+    chunk = 8: sp3d_wino_fused_split (lane halves), chunk = 16: sp3d_wino_fused_split64 (lane quarters)"""
     P, Cc, O = (int(v) for v in U.shape)
     U = U.float()
     hi = U.bfloat16()
     r = U - hi.float()
     mid = r.bfloat16()
     lo = (r - mid.float()).bfloat16()
-    pieces = torch.stack([mid, hi, lo], 0).reshape(3, P, Cc // 8, 2, 4, O)          # [piece, p, chunk, half, q, o]
-    return pieces.permute(1, 2, 3, 5, 0, 4).contiguous()                               # [p, chunk, half, o, piece, q]
+    pieces = torch.stack([mid, hi, lo], 0).reshape(3, P, Cc // chunk, chunk // 4, 4, O)   # [piece, p, chunk, group, q, o]
+    return pieces.permute(1, 2, 3, 5, 0, 4).contiguous()                                  # [p, chunk, group, o, piece, q]
 
 
 def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
@@ -620,8 +621,9 @@ def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: in
 
 def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
                        residual: Optional[torch.Tensor] = None, U3: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """one-launch Winograd 3x3x3 conv (C = 16 | 32 -> O = 32) of channels_last_3d x with the fused epilogue; with U3
-    (wino_weights_split(U)) the products run as exact three-piece bf16 splits on the bf16 matrix pipe"""
+    """one-launch Winograd 3x3x3 conv (C = 16 | 32 -> O = 32; with U3 also C = 32 | 64 -> O = 64) of channels_last_3d x
+    with the fused epilogue; with U3 (wino_weights_split(U, 8 | 16)) the products run as exact three-piece bf16 splits
+    on the bf16 matrix pipe"""
     lib = load()
     _require_cuda(x, "x")
     B, Cc, X, Y, Z = (int(v) for v in x.shape)
@@ -631,6 +633,13 @@ def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mo
     y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
         residual = residual.contiguous(memory_format=torch.channels_last_3d)
+    if U3 is not None and O == 64:
+        lib.sp3d_wino_fused_split64.restype = C.c_int
+        lib.sp3d_wino_fused_split64.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
+        check(lib.sp3d_wino_fused_split64(x.data_ptr(), U3.data_ptr(), y.data_ptr(), shift.data_ptr(),
+                                          residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
+                                          _stream(x.device)), "sp3d_wino_fused_split64")
+        return y
     if U3 is not None:
         lib.sp3d_wino_fused_split.restype = C.c_int
         lib.sp3d_wino_fused_split.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]

@@ -566,6 +566,228 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fused Winograd F(2x2x2,3x3x3) for the HALF-resolution layers (C = 32 | 64 -> O = 64 on 40x40x10): the three-launch form
+// (input transform, 64 batched GEMMs, output transform) moves the 131 MB transformed tensor four times (115 us per
+// layer, HBM/MALL-bound); here nothing transformed leaves the CU.  Same scheme as wino_fused3_kernel - regions staged in
+// LDS, operands built on the fly, exact three-piece bf16 splits, x fold on the matrix pipe, y,z fold on the VALU - on
+// v_mfma_f32_16x16x32_bf16: a block is 4x4x1 tiles (8x8x2 outputs) x 64 output channels, chunks of 16 input channels
+// (lane = tile x 4-channel group), and the NW waves of a workgroup share the staged region, each owning 64/NW outputs,
+// so that the per-lane operand work (transforms + splits) is amortised over 16*NBW outputs.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int W16_RX = 10, W16_RY = 10, W16_RZ = 4, W16_VS = 16;
+constexpr int W16_ROW = W16_RX * W16_VS + 4;
+constexpr int W16_LDS = W16_RY * W16_RZ * W16_ROW;               // 6 560 floats = 26 240 B
+
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int C, int MODE, int NBW, int KS>
+__global__ __launch_bounds__(64 * (4 / NBW) * KS) void wino_fused16_kernel(const float *__restrict__ x,
+                                                                          const unsigned *__restrict__ U3,
+                                                                          float *__restrict__ y, const float *__restrict__ shift,
+                                                                          const float *__restrict__ res, int B, int X, int Y,
+                                                                          int Z, int NBX, int NBY, int NBZ)
+{
+    // workgroup = KS channel groups x (4 / NBW) output groups of one wave each: channel group kg owns the 16-channel
+    // chunks kg, kg + KS, ... (its own staged region), output group ow owns outputs 16*NBW*ow ...; the KS partial sums
+    // meet in LDS at the end.  More waves per block without repeating the operand work: the grid of a half-resolution
+    // layer is only 500 blocks.
+    constexpr int O = 64, NCH = C / 16, NOW = 4 / NBW, NTG = 64 * NOW;
+    static_assert(NCH % KS == 0, "chunks must divide evenly over the channel groups");
+    __shared__ __attribute__((aligned(16))) float lds[KS * W16_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = wave / NOW, ow = wave % NOW, tg = tid - kg * NTG;          // thread index inside the channel group
+    float *region = lds + kg * W16_LDS;
+    const int tl = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int bz = bid % NBZ; bid /= NBZ;
+    const int by = bid % NBY; bid /= NBY;
+    const int bx = bid % NBX;
+    const int b = bid / NBX;
+    const int ttx = tl & 3, tty = tl >> 2;
+    const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 2;
+    const float *rb = region + (2 * tty) * W16_ROW + (2 * ttx) * W16_VS + 4 * q;
+
+    f32x4 acc[8][NBW];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[a][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // region of one 16-channel chunk: 400 voxels x 4 float4; every thread of the channel group owns PER of them.  The
+    // loads of the group's next chunk are issued before the 16 steps of the current one and parked in registers (a
+    // dependent load->store loop costs as much as the steps themselves: ~2 us of memory latency per iteration)
+    constexpr int NV4 = W16_RX * W16_RY * W16_RZ * 4, PER = (NV4 + NTG - 1) / NTG;
+    int goff[PER], loff[PER];                      // global offset (floats, chunk 0; -1: padding) and LDS offset (-1: none)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = tg + u * NTG;
+        const int v = idx >> 2, part = idx & 3;
+        const int vx = v % W16_RX, vy = (v / W16_RX) % W16_RY, vz = v / (W16_RX * W16_RY);
+        const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
+        const bool in = idx < NV4 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+        goff[u] = in ? (int)(((((int64_t)gx) * Y + gy) * Z + gz) * C + part * 4) : -1;
+        loff[u] = idx < NV4 ? (vz * W16_RY + vy) * W16_ROW + vx * W16_VS + part * 4 : -1;
+    }
+    const float *xb = x + (int64_t)b * X * Y * Z * C;
+    float4 pre[PER];
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            pre[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (goff[u] >= 0) pre[u] = *reinterpret_cast<const float4 *>(xb + goff[u] + cc * 16);
+        }
+    };
+    fetch(kg);
+#pragma unroll 1
+    for (int cc = kg; cc < NCH; cc += KS) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (loff[u] >= 0) *reinterpret_cast<float4 *>(region + loff[u]) = pre[u];
+        __syncthreads();
+        if (cc + KS < NCH) fetch(cc + KS);
+        // record of (point p, chunk cc, channel group q, output o): 6 dwords [mid(4ch) hi(4ch) lo(4ch)]
+        const unsigned *ub = U3 + ((((int64_t)cc * 4 + q) * O) + ow * NBW * 16 + tl) * 6;
+        auto load_b = [&](int i, int jk, int n) {
+            const unsigned *r = ub + (int64_t)(i * 16 + jk) * NCH * 4 * O * 6 + n * 16 * 6;
+            WfB w;
+            w.mh = *reinterpret_cast<const u32x4_a8 *>(r);
+            w.l = *reinterpret_cast<const u32x2_a8 *>(r + 4);
+            return w;
+        };
+#pragma unroll 1
+        for (int jk = 0; jk < 16; ++jk) {
+            const int j = jk >> 2, k = jk & 3;
+            // this step's weights: in flight while the operands are built (~1000 cycles)
+            WfB bw[NBW][4];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bw[n][i] = load_b(i, jk, n);
+            const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
+            const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
+            const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
+            const float *r00 = rb + (za * W16_RY + ya) * W16_ROW, *r10 = rb + (za * W16_RY + yb) * W16_ROW;
+            const float *r01 = rb + (zb * W16_RY + ya) * W16_ROW, *r11 = rb + (zb * W16_RY + yb) * W16_ROW;
+            float g[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * W16_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * W16_VS);
+                const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * W16_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * W16_VS);
+                g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
+                g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
+                g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
+                g[xi][3] = fmaf(sz, fmaf(sy, v11.w, v01.w), fmaf(sy, v10.w, v00.w));
+            }
+            float cyz[4];
+#pragma unroll
+            for (int bc = 0; bc < 4; ++bc) {
+                const int bb = bc >> 1, c2 = bc & 1;
+                const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
+                const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
+                cyz[bc] = cy * cz;
+            }
+            f32x4 M0[NBW], M1[NBW];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) { M0[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; M1[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float av[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    av[kk] = (i == 1) ? g[1][kk] + g[2][kk] : ((i == 3) ? g[3][kk] - g[1][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk]);
+                const unsigned hi01 = pack_bf16(av[0], av[1]), hi23 = pack_bf16(av[2], av[3]);
+                const float r0 = av[0] - bf16_lo(hi01), r1 = av[1] - bf16_hi(hi01), r2 = av[2] - bf16_lo(hi23), r3 = av[3] - bf16_hi(hi23);
+                const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
+                const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
+                const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+                const u32x4 Qhh = {hi01, hi23, hi01, hi23}, Qmm = {mid01, mid23, mid01, mid23}, Qlh = {lo01, lo23, hi01, hi23};
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    const WfB &w = bw[n][i];
+                    const u32x4 Bmh = w.mh;
+                    const u32x4 Bhl = {w.mh.z, w.mh.w, w.l.x, w.l.y};
+                    if (i < 3) {
+                        M0[n] = mfma16_bf16(Qhh, Bmh, M0[n]);
+                        M0[n] = mfma16_bf16(Qmm, Bmh, M0[n]);
+                        M0[n] = mfma16_bf16(Qlh, Bhl, M0[n]);
+                    }
+                    if (i == 1 || i == 3) {
+                        M1[n] = mfma16_bf16(Qhh, Bmh, M1[n]);
+                        M1[n] = mfma16_bf16(Qmm, Bmh, M1[n]);
+                        M1[n] = mfma16_bf16(Qlh, Bhl, M1[n]);
+                    }
+                    if (i == 2) {
+                        const u32x4 nmh = Bmh ^ 0x80008000u, nhl = Bhl ^ 0x80008000u;
+                        M1[n] = mfma16_bf16(Qhh, nmh, M1[n]);
+                        M1[n] = mfma16_bf16(Qmm, nmh, M1[n]);
+                        M1[n] = mfma16_bf16(Qlh, nhl, M1[n]);
+                    }
+                }
+            }
+            // the coefficients are 0 or +-1 and wave-uniform; multiplying by the zeros costs less than branching or
+            // selecting around them on accumulators this small
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int bc = 0; bc < 4; ++bc) {
+                    const f32x4 cv = {cyz[bc], cyz[bc], cyz[bc], cyz[bc]};
+                    acc[bc][n] = __builtin_elementwise_fma(M0[n], cv, acc[bc][n]);
+                    acc[4 + bc][n] = __builtin_elementwise_fma(M1[n], cv, acc[4 + bc][n]);
+                }
+        }
+    }
+
+    if (KS > 1) {                                   // partial sums of channel groups 1.. -> group 0, through LDS
+        __syncthreads();                            // every region has been read for the last time
+        f32x4 *red = reinterpret_cast<f32x4 *>(lds);
+        if (kg > 0) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) red[(((kg - 1) * NOW + ow) * 8 * NBW + a * NBW + n) * 64 + lane] = acc[a][n];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KS; ++g2)
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) acc[a][n] += red[(((g2 - 1) * NOW + ow) * 8 * NBW + a * NBW + n) * 64 + lane];
+    }
+
+    // D of the 16x16 MFMA: lane (col = lane & 15, group = lane >> 4) holds tiles 4*group + v, output 16*nb + col
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+        const int o = (ow * NBW + n) * 16 + tl;
+        const float sh = shift[o];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int tile = 4 * q + v;
+                const int rx = tile & 3, ry = tile >> 2;
+                const int xo = ox0 + 2 * rx + (a >> 2), yo = oy0 + 2 * ry + ((a >> 1) & 1), zo = oz0 + (a & 1);
+                if (xo < X && yo < Y && zo < Z) {
+                    const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o;
+                    float val = acc[a][n][v] + sh;
+                    if (MODE == 2) val += res[idx];
+                    if (MODE >= 1) val = fmaxf(val, 0.0f);
+                    if (MODE == 3) val += res[idx];
+                    y[idx] = val;
+                }
+            }
+        }
+    }
+}
+
 } // namespace sp3d
 
 extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
@@ -617,6 +839,50 @@ extern "C" int sp3d_wino_fused_split(const float *x, const void *U3, float *y, c
 #define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }
     if (C == 16) { SP3D_WFM(16) } else { SP3D_WFM(32) }
 #undef SP3D_WFM
+#undef SP3D_WF
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+static int g_w16_nbw = 0, g_w16_ks = 1;          // 0: chosen per launch (below); tools/exp_wino_split.py overrides
+extern "C" int sp3d_debug_set_w16_nbw(int nbw, int ks)
+{
+    if ((nbw != 0 && nbw != 1 && nbw != 2 && nbw != 4) || (ks != 1 && ks != 2)) return SP3D_EINVAL;
+    g_w16_nbw = nbw;
+    g_w16_ks = ks;
+    return SP3D_OK;
+}
+
+extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const float *shift, const float *residual,
+                                       int mode, int B, int X, int Y, int Z, int C, int O, void *stream)
+{
+    using namespace sp3d;
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
+    if (!x || !U3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if (O != 64 || (C != 32 && C != 64) || (reinterpret_cast<uintptr_t>(U3) & 7)) return SP3D_EUNSUPPORTED;
+    const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 1) / 2;
+    const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
+    if (blocks > 0x7fffffff) return SP3D_ERANGE;
+    // waves per block: few blocks (the root net's half-resolution grid: 500) -> split the input channels over two wave
+    // groups so that every SIMD has work; many blocks (the pose net's cubes) -> one wave per block, no reduction.
+    // Measured at (4,64,40,40,10) / (4,32,40,40,10) / (8,64,32,32,32): tools/exp_wino_split.py --half
+    int nbw = g_w16_nbw, ks = g_w16_ks;
+    if (nbw == 0) {
+        if (blocks >= 1024) { nbw = 4; ks = 1; }
+        else if (C == 64) { nbw = 4; ks = 2; }
+        else { nbw = 2; ks = 2; }
+    }
+    if ((C / 16) % ks) return SP3D_EUNSUPPORTED;
+    const dim3 grid((unsigned)blocks), block(64 * (4 / nbw) * ks);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned *u3 = reinterpret_cast<const unsigned *>(U3);
+#define SP3D_WF(C_, M_, N_, K_) hipLaunchKernelGGL((wino_fused16_kernel<C_, M_, N_, K_>), grid, block, 0, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
+#define SP3D_WFN(C_, M_) { if (nbw == 1 && ks == 1) SP3D_WF(C_, M_, 1, 1); else if (nbw == 2 && ks == 1) SP3D_WF(C_, M_, 2, 1); else if (nbw == 4 && ks == 1) SP3D_WF(C_, M_, 4, 1); \
+                           else if (nbw == 2 && ks == 2) SP3D_WF(C_, M_, 2, 2); else if (nbw == 4 && ks == 2) SP3D_WF(C_, M_, 4, 2); else return SP3D_EUNSUPPORTED; }
+#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WFN(C_, 0); break; case 1: SP3D_WFN(C_, 1); break; case 2: SP3D_WFN(C_, 2); break; default: SP3D_WFN(C_, 3); }
+    if (C == 32) { SP3D_WFM(32) } else { SP3D_WFM(64) }
+#undef SP3D_WFM
+#undef SP3D_WFN
 #undef SP3D_WF
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;

@@ -1020,3 +1020,35 @@ def test_winograd_fused_split_kernel_has_fp32_accuracy(shape):
     assert y3.shape == ref.shape and y3.is_contiguous(memory_format=torch.channels_last_3d)
     assert e3 <= 5e-5 * max(1.0, float(ref.abs().max()))
     assert e3 <= 1.5 * e32 + 1e-7, (e3, e32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, (16, 16, 4), 1), (1, 32, (9, 7, 5), 2), (1, 64, (8, 8, 2), 3), (2, 32, (24, 8, 6), 0),
+                                   (1, 64, (40, 40, 10), 2)])
+def test_winograd_fused_split64_kernel(shape):
+    """sp3d_wino_fused_split64 (half-resolution layers, 16x16x32 bf16 MFMA, three exact pieces) == conv3d + epilogue vs a
+    float64 referee; block-edge and odd sizes included"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, (X, Y, Z), mode = shape
+    O = 64
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = (torch.randn((B, C, X, Y, Z), generator=g) * 2.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((O, C, 3, 3, 3), generator=g) * 0.05).cuda()
+    shift = torch.randn((O,), generator=g).cuda()
+    res = torch.randn((B, O, X, Y, Z), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    U = _lib.wino_weights(w)
+    U3 = _lib.wino_weights_split(U, 16)
+    ref = F.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, O, 1, 1, 1)
+    if mode == 2:
+        ref = ref + res.double()
+    if mode >= 1:
+        ref = ref.clamp_min(0)
+    if mode == 3:
+        ref = ref + res.double()
+    y = _lib.wino_fused_conv3d_(x, U, shift, mode, res if mode >= 2 else None, U3)
+    three = _lib.wino_conv3d_(x, U, shift, mode, res if mode >= 2 else None)          # the three-launch fp32 form
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    e, e3 = float((y.double() - ref).abs().max()), float((three.double() - ref).abs().max())
+    assert e <= 5e-5 * max(1.0, float(ref.abs().max()))
+    assert e <= 1.5 * e3 + 1e-7, (e, e3)

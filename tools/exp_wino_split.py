@@ -23,7 +23,7 @@ def timeit(fn, iters=30):
 
 
 out = {}
-for name, (B, C, X, Y, Z, mode) in {"root_32_relu": (4, 32, 80, 80, 20, 1), "root_32_res": (4, 32, 80, 80, 20, 2),
+for name, (B, C, X, Y, Z, mode) in {} if "--half" in sys.argv else {"root_32_relu": (4, 32, 80, 80, 20, 1), "root_32_res": (4, 32, 80, 80, 20, 2),
                                     "root_16_relu": (4, 16, 80, 80, 20, 1), "pose8_32_res": (8, 32, 64, 64, 64, 2)}.items():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, C, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
@@ -48,4 +48,21 @@ for name, (B, C, X, Y, Z, mode) in {"root_32_relu": (4, 32, 80, 80, 20, 1), "roo
         r.update(max_err_fp32_mfma=float((y32 - ref).abs().max()), max_err_bf16x3=float((y3 - ref).abs().max()),
                  max_err_direct_fp32_conv=float((d - ref).abs().max()), ref_max=float(ref.abs().max()))
     out[name] = r
+for name, (B, C, X, Y, Z, mode) in {"half_64_res": (4, 64, 40, 40, 10, 2), "half_64_relu": (4, 64, 40, 40, 10, 1),
+                                    "half_32to64_relu": (4, 32, 40, 40, 10, 1), "pose8_half_64": (8, 64, 32, 32, 32, 2)}.items():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).cuda()
+    shift = torch.randn(64, generator=g).cuda()
+    res = torch.randn(B, 64, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d) if mode >= 2 else None
+    U = _lib.wino_weights(w)
+    U3 = _lib.wino_weights_split(U, 16)
+    r = {}
+    for nbw, ks in ((1, 1), (2, 1), (4, 1), (2, 2), (4, 2)):
+        _lib.load().sp3d_debug_set_w16_nbw(nbw, ks)
+        r[f"fused_bf16x3_nbw{nbw}_ks{ks}_us"] = timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3))
+    _lib.load().sp3d_debug_set_w16_nbw(0, 1)
+    r["fused_bf16x3_auto_us"] = timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3))
+    out[name] = {**r, "three_launch_fp32_us": timeit(lambda: _lib.wino_conv3d_(x, U, shift, mode, res)),
+                 "miopen_direct_us": timeit(lambda: F.conv3d(x, w.contiguous(memory_format=torch.channels_last_3d), None, 1, 1))}
 print(json.dumps(out, indent=1))
