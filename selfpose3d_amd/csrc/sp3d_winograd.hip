@@ -576,6 +576,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // (lane = tile x 4-channel group), and the NW waves of a workgroup share the staged region, each owning 64/NW outputs,
 // so that the per-lane operand work (transforms + splits) is amortised over 16*NBW outputs.
 // ------------------------------------------------------------------------------------------
+#ifndef SP3D_W16_ABLATE
+#define SP3D_W16_ABLATE 0      // measurement builds only (tools/diag_w16.py): 1 no MFMA, 2 no weight loads, 4 no split, 8 no LDS reads
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W16_RX = 10, W16_RY = 10, W16_RZ = 4, W16_VS = 16;
 constexpr int W16_ROW = W16_RX * W16_VS + 4;
@@ -587,7 +590,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c)
 }
 
 template <int C, int MODE, int NBW, int KS>
-__global__ __launch_bounds__(64 * (4 / NBW) * KS) void wino_fused16_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_per_eu(NBW <= 2 ? 2 : 1))) void wino_fused16_kernel(const float *__restrict__ x,
                                                                           const unsigned *__restrict__ U3,
                                                                           float *__restrict__ y, const float *__restrict__ shift,
                                                                           const float *__restrict__ res, int B, int X, int Y,
@@ -669,7 +672,14 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) void wino_fused16_kernel(const
 #pragma unroll
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bw[n][i] = load_b(i, jk, n);
+                for (int i = 0; i < 4; ++i) {
+#if SP3D_W16_ABLATE & 2
+                    bw[n][i].mh = u32x4{0x3f803f80u + (unsigned)(jk + n), 0x3f803f80u, 0x3f803f80u + (unsigned)i, 0x3f803f80u};
+                    bw[n][i].l = u32x2{0x3f803f80u, 0x3f803f80u};
+#else
+                    bw[n][i] = load_b(i, jk, n);
+#endif
+                }
             const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
             const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
             const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
@@ -678,8 +688,14 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) void wino_fused16_kernel(const
             float g[4][4];
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) {
+#if SP3D_W16_ABLATE & 8
+                const float f0 = __int_as_float(0x3f800000 + jk + xi), f1 = __int_as_float(0x3f900000 + lane);
+                const float4 v00 = make_float4(f0, f1, f0, f1), v10 = make_float4(f1, f0, f1, f0), v01 = v00, v11 = v10;
+                (void)r00; (void)r10; (void)r01; (void)r11;
+#else
                 const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * W16_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * W16_VS);
                 const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * W16_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * W16_VS);
+#endif
                 g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
                 g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
                 g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
@@ -703,16 +719,28 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) void wino_fused16_kernel(const
                 for (int kk = 0; kk < 4; ++kk)
                     av[kk] = (i == 1) ? g[1][kk] + g[2][kk] : ((i == 3) ? g[3][kk] - g[1][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk]);
                 const unsigned hi01 = pack_bf16(av[0], av[1]), hi23 = pack_bf16(av[2], av[3]);
+#if SP3D_W16_ABLATE & 4
+                const unsigned mid01 = hi01, mid23 = hi23, lo01 = hi01, lo23 = hi23;
+#else
                 const float r0 = av[0] - bf16_lo(hi01), r1 = av[1] - bf16_hi(hi01), r2 = av[2] - bf16_lo(hi23), r3 = av[3] - bf16_hi(hi23);
                 const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
                 const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
                 const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+#endif
                 const u32x4 Qhh = {hi01, hi23, hi01, hi23}, Qmm = {mid01, mid23, mid01, mid23}, Qlh = {lo01, lo23, hi01, hi23};
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const WfB &w = bw[n][i];
                     const u32x4 Bmh = w.mh;
                     const u32x4 Bhl = {w.mh.z, w.mh.w, w.l.x, w.l.y};
+#if SP3D_W16_ABLATE & 1
+                    {   // no matrix instructions: keep every operand alive with one integer op each
+                        const unsigned z = (Qhh.x ^ Bmh.x) + (Qmm.y ^ Bmh.z) + (Qlh.x ^ Bhl.w) + (Qlh.z ^ Bhl.y);
+                        M0[n].x += __uint_as_float(z & 0x3fffffffu);
+                        M1[n].y += __uint_as_float((z >> 1) & 0x3fffffffu);
+                        continue;
+                    }
+#endif
                     if (i < 3) {
                         M0[n] = mfma16_bf16(Qhh, Bmh, M0[n]);
                         M0[n] = mfma16_bf16(Qmm, Bmh, M0[n]);
@@ -863,14 +891,11 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
     const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 1) / 2;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
-    // waves per block: few blocks (the root net's half-resolution grid: 500) -> split the input channels over two wave
-    // groups so that every SIMD has work; many blocks (the pose net's cubes) -> one wave per block, no reduction.
+    // waves per block: two output groups x two input-channel groups of one wave each (2 waves per SIMD resident).
     // Measured at (4,64,40,40,10) / (4,32,40,40,10) / (8,64,32,32,32): tools/exp_wino_split.py --half
     int nbw = g_w16_nbw, ks = g_w16_ks;
     if (nbw == 0) {
-        if (blocks >= 1024) { nbw = 4; ks = 1; }
-        else if (C == 64) { nbw = 4; ks = 2; }
-        else { nbw = 2; ks = 2; }
+        nbw = 2; ks = 2;               // 4 waves per block, 2 per SIMD: best on all three shapes
     }
     if ((C / 16) % ks) return SP3D_EUNSUPPORTED;
     const dim3 grid((unsigned)blocks), block(64 * (4 / nbw) * ks);
