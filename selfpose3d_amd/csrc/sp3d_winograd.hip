@@ -173,6 +173,10 @@ extern "C" int sp3d_wino_output(const float *M, float *y, const float *shift, co
 //   the inverse transform is linear: along x it is folded into the MFMA accumulation, along y,z it is applied to
 //     the accumulators on the VALU; nothing transformed is ever stored.
 // ------------------------------------------------------------------------------------------
+#ifndef SP3D_W16_ABLATE
+#define SP3D_W16_ABLATE 0      // measurement builds only (tools/diag_w16.py): 1 no MFMA, 2 no weight loads, 4 no split, 8 no LDS reads
+#endif
+
 namespace sp3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -419,6 +423,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int cc = 0; cc < NCH; ++cc) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // stage 600 voxels x 8 channels = 1200 float4, 5 loads in flight per lane (10 or all 19 at once measured no
+        // faster: the accumulators start to spill)
 #pragma unroll 1
         for (int i0 = 0; i0 < WF_RX * WF_RY * WF_RZ * 2; i0 += 64 * 5) {
             float4 d[5];
@@ -449,8 +455,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         auto load_b = [&](int i, int jk) {
             const unsigned *r = ub + (int64_t)(i * 16 + jk) * NCH * 2 * 32 * 6;
             WfB w;
+#if SP3D_W16_ABLATE & 2
+            (void)r;
+            w.mh = u32x4{0x3f803f80u + (unsigned)jk, 0x3f803f80u, 0x3f803f80u + (unsigned)i, 0x3f803f80u};
+            w.l = u32x2{0x3f803f80u, 0x3f803f80u};
+#else
             w.mh = *reinterpret_cast<const u32x4_a8 *>(r);
             w.l = *reinterpret_cast<const u32x2_a8 *>(r + 4);
+#endif
             return w;
         };
         // B of x points 0,1 arrives one step ahead; B of x points 2,3 is fetched at the top of its own step (it is
@@ -468,8 +480,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             float g[4][4];
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) {
+#if SP3D_W16_ABLATE & 8
+                const float f0 = __int_as_float(0x3f800000 + jk + xi), f1 = __int_as_float(0x3f900000 + lane);
+                const float4 v00 = make_float4(f0, f1, f0, f1), v10 = make_float4(f1, f0, f1, f0), v01 = v00, v11 = v10;
+                (void)r00; (void)r10; (void)r01; (void)r11;
+#else
                 const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * WF_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * WF_VS);
                 const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * WF_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * WF_VS);
+#endif
                 g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
                 g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
                 g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
@@ -495,14 +513,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     av[kk] = (i == 1) ? g[1][kk] + g[2][kk] : ((i == 3) ? g[3][kk] - g[1][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk]);
                 // a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits)
                 const unsigned hi01 = pack_bf16(av[0], av[1]), hi23 = pack_bf16(av[2], av[3]);
+#if SP3D_W16_ABLATE & 4
+                const unsigned mid01 = hi01, mid23 = hi23, lo01 = hi01, lo23 = hi23;
+#else
                 const float r0 = av[0] - bf16_lo(hi01), r1 = av[1] - bf16_hi(hi01), r2 = av[2] - bf16_lo(hi23), r3 = av[3] - bf16_hi(hi23);
                 const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
                 const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
                 const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+#endif
                 const u32x4 Qhh = {hi01, hi23, hi01, hi23}, Qmm = {mid01, mid23, mid01, mid23}, Qlh = {lo01, lo23, hi01, hi23};
                 const WfB &w = (i < 2) ? bcur[i] : blate[i - 2];
                 const u32x4 Bmh = w.mh;
                 const u32x4 Bhl = {w.mh.z, w.mh.w, w.l.x, w.l.y};
+#if SP3D_W16_ABLATE & 1
+                {   // no matrix instructions: keep every operand alive with one integer op each
+                    const unsigned z = (Qhh.x ^ Bmh.x) + (Qmm.y ^ Bmh.z) + (Qlh.x ^ Bhl.w) + (Qlh.z ^ Bhl.y);
+                    M0[0] += __uint_as_float(z & 0x3fffffffu);
+                    M1[1] += __uint_as_float((z >> 1) & 0x3fffffffu);
+                    if (i == 1) {
+                        bnxt[0] = load_b(0, jk_next);
+                        bnxt[1] = load_b(1, jk_next);
+                    }
+                    continue;
+                }
+#endif
                 if (i < 3) {
                     M0 = mfma_bf16(Qhh, Bmh, M0);
                     M0 = mfma_bf16(Qmm, Bmh, M0);
@@ -576,9 +610,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // (lane = tile x 4-channel group), and the NW waves of a workgroup share the staged region, each owning 64/NW outputs,
 // so that the per-lane operand work (transforms + splits) is amortised over 16*NBW outputs.
 // ------------------------------------------------------------------------------------------
-#ifndef SP3D_W16_ABLATE
-#define SP3D_W16_ABLATE 0      // measurement builds only (tools/diag_w16.py): 1 no MFMA, 2 no weight loads, 4 no split, 8 no LDS reads
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int W16_RX = 10, W16_RY = 10, W16_RZ = 4, W16_VS = 16;
 constexpr int W16_ROW = W16_RX * W16_VS + 4;

@@ -30,6 +30,32 @@ if "--build-only" in sys.argv:
     sys.exit(0)
 import torch
 from selfpose3d_amd import _lib
+if "--full-res" in sys.argv:       # the full-resolution kernel (wino_fused3_kernel) under the same switches
+    B, C, X, Y, Z = 4, 32, 80, 80, 20
+    x = torch.randn(B, C, X, Y, Z).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(32, C, 3, 3, 3) * 0.05).cuda()
+    U3 = _lib.wino_weights_split(_lib.wino_weights(w))
+    shift = torch.randn(32).cuda()
+    y = torch.empty(B, X, Y, Z, 32, device="cuda")
+    out = {}
+    for name, m in MASKS.items():
+        L = ctypes.CDLL(lib_path(m))
+        f = L.sp3d_wino_fused_split
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        run = lambda: f(x.data_ptr(), U3.data_ptr(), y.data_ptr(), shift.data_ptr(), None, 1, B, X, Y, Z, C, 32, None)
+        for _ in range(3):
+            assert run() == 0
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 B, C, X, Y, Z = 4, 64, 40, 40, 10
 x = torch.randn(B, C, X, Y, Z).cuda().contiguous(memory_format=torch.channels_last_3d)
 w = (torch.randn(64, C, 3, 3, 3) * 0.05).cuda()
