@@ -419,32 +419,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[a][v] = 0.0f;
 
+    // staging constants of this lane: region voxel (x = u >> 1, y = 5 * (u & 1) + sr, z = sz_), channel half sh_
+    const int sh_ = lane & 1, sz_ = (lane >> 1) % WF_RZ, sr = (lane >> 1) / WF_RZ;       // lanes 60..63 idle
+    const int sgz = oz0 - 1 + sz_, sgy0 = oy0 - 1 + sr, sgy1 = sgy0 + 5;
+    const bool sg_inz = sgz >= 0 && sgz < Z, sg_iny0 = sgy0 >= 0 && sgy0 < Y, sg_iny1 = sgy1 >= 0 && sgy1 < Y;
+    const int64_t sg_base = ((((int64_t)b * X + (ox0 - 1)) * Y + sgy0) * Z + sgz) * C + sh_ * 4;
+    const int sg_lds = (sz_ * WF_RY + sr) * WF_ROW + sh_ * 4;
+
 #pragma unroll 1
     for (int cc = 0; cc < NCH; ++cc) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // stage 600 voxels x 8 channels = 1200 float4, 5 loads in flight per lane (10 or all 19 at once measured no
-        // faster: the accumulators start to spill)
+        // faster: the accumulators start to spill).  Lane = (half, z, column-of-5): the (x,y) column of batch element u
+        // is (u >> 1, 5 * (u & 1) + r), so every address is a per-lane constant plus a compile-time offset - the former
+        // idx -> (x,y,z) divisions cost 60 VALU instructions per element, a fifth of the kernel's instruction count
+        {
+            const bool on = lane < 60;
+            const int64_t gbase = sg_base + cc * 8;                           // + (x * Y + y5) * Z * C per element
 #pragma unroll 1
-        for (int i0 = 0; i0 < WF_RX * WF_RY * WF_RZ * 2; i0 += 64 * 5) {
-            float4 d[5];
+            for (int u0 = 0; u0 < 20; u0 += 5) {
+                float4 d[5];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int idx = i0 + u * 64 + lane;
-                const int v = idx >> 1, half = idx & 1;
-                const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
-                const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
-                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (idx < WF_RX * WF_RY * WF_RZ * 2 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z)
-                    d[u] = *reinterpret_cast<const float4 *>(x + ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + cc * 8 + half * 4);
-            }
+                for (int uu = 0; uu < 5; ++uu) {
+                    const int u = u0 + uu;
+                    const int gx = ox0 - 1 + (u >> 1);
+                    const bool iny = (u & 1) ? sg_iny1 : sg_iny0;
+                    d[uu] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (on && sg_inz && iny && gx >= 0 && gx < X)
+                        d[uu] = *reinterpret_cast<const float4 *>(x + gbase + ((int64_t)(u >> 1) * Y + 5 * (u & 1)) * Z * C);
+                }
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int idx = i0 + u * 64 + lane;
-                if (idx < WF_RX * WF_RY * WF_RZ * 2) {
-                    const int v = idx >> 1, half = idx & 1;
-                    const int vx = v % WF_RX, vy = (v / WF_RX) % WF_RY, vz = v / (WF_RX * WF_RY);
-                    *reinterpret_cast<float4 *>(region + (vz * WF_RY + vy) * WF_ROW + vx * WF_VS + half * 4) = d[u];
+                for (int uu = 0; uu < 5; ++uu) {
+                    const int u = u0 + uu;
+                    if (on) *reinterpret_cast<float4 *>(region + sg_lds + 5 * (u & 1) * WF_ROW + (u >> 1) * WF_VS) = d[uu];
                 }
             }
         }
@@ -580,16 +588,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
 
+    // accumulator element (a, v) of lane (t, h) is output voxel (ox0 + dx, oy0 + 2h + dy, oz0 + dz), channel t, with
+    // dx = 2 (v & 3) + (a >> 2), dy = 4 ((v >> 2) & 1) + ((a >> 1) & 1), dz = 2 (v >> 3) + (a & 1) known at compile time:
+    // one per-lane base address, wave-uniform offsets and bounds (only the y bound depends on the lane)
     const float sh = shift[t];
+    const int yl = oy0 + 2 * h;
+    const int64_t obase = ((((int64_t)b * X + ox0) * Y + yl) * Z + oz0) * O + t;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int row = 8 * (v >> 2) + (v & 3) + 4 * h;
-            const int rx = row & 3, ry = (row >> 2) & 3, rz = row >> 4;
-            const int xo = ox0 + 2 * rx + (a >> 2), yo = oy0 + 2 * ry + ((a >> 1) & 1), zo = oz0 + 2 * rz + (a & 1);
-            if (xo < X && yo < Y && zo < Z) {
-                const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t;
+            const int dx = 2 * (v & 3) + (a >> 2), dy = 4 * ((v >> 2) & 1) + ((a >> 1) & 1), dz = 2 * (v >> 3) + (a & 1);
+            if (ox0 + dx < X && oz0 + dz < Z && yl + dy < Y) {
+                const int64_t idx = obase + (((int64_t)dx * Y + dy) * Z + dz) * O;
                 float val = acc[a][v] + sh;
                 if (MODE == 2) val += res[idx];
                 if (MODE >= 1) val = fmaxf(val, 0.0f);
@@ -600,8 +611,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
 // Fused Winograd F(2x2x2,3x3x3) for the HALF-resolution layers (C = 32 | 64 -> O = 64 on 40x40x10): the three-launch form
 // (input transform, 64 batched GEMMs, output transform) moves the 131 MB transformed tensor four times (115 us per
 // layer, HBM/MALL-bound); here nothing transformed leaves the CU.  Same scheme as wino_fused3_kernel - regions staged in
