@@ -329,6 +329,14 @@ int sp3d_wino_fused_split(const float *x, const void *U3, float *y, const float 
 int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const float *shift, const float *residual, int mode,
                             int B, int X, int Y, int Z, int C, int O, void *stream);
 
+/* Direct 3x3x3 stride-1 'same' convolution (v2v_net.py:23-45 Res3DBlock convs) + the fused epilogue of
+ * sp3d_channel_shift_act, as an implicit GEMM on v_mfma_f32_32x32x16_bf16 with exact three-piece bf16 splits of both
+ * operands (fp32 accuracy, fp32 accumulation; no Winograd transforms).  x, y channels-last (B,X,Y,Z,C) / (B,X,Y,Z,O);
+ * W3: 48-byte records of bf16 = the three B operands {hi,lo} {hi,hi} {mid,mid} (4 channels each) at index
+ * ((tap*(C/8) + chunk)*2 + half)*O + o, tap = kz*9 + ky*3 + kx of w[o][c][kx][ky][kz] (_lib.conv_weights_split), 16-byte aligned.  (C,O) in {(16,32),(32,32)}. */
+int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode, int B,
+                     int X, int Y, int Z, int C, int O, void *stream);
+
 /*
  * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
  * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):

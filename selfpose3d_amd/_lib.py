@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -594,6 +594,36 @@ def wino_weights_split(U: torch.Tensor, chunk: int = 8) -> torch.Tensor:
     lo = (r - mid.float()).bfloat16()
     pieces = torch.stack([mid, hi, lo], 0).reshape(3, P, Cc // chunk, chunk // 4, 4, O)   # [piece, p, chunk, group, q, o]
     return pieces.permute(1, 2, 3, 5, 0, 4).contiguous()                                  # [p, chunk, group, o, piece, q]
+
+
+def conv_weights_split(w: torch.Tensor) -> torch.Tensor:
+    """(O,C,3,3,3) conv weights -> the bf16 operand records sp3d_conv3_split reads: (27, C/8, 2, O, 6, 4) bfloat16 = the
+    three B operands {hi,lo} {hi,hi} {mid,mid} of 4 channels each, tap = kz*9 + ky*3 + kx, channel = 8*chunk + 4*half + q"""
+    O, Cc = int(w.shape[0]), int(w.shape[1])
+    pc = wino_weights_split(w.float().permute(4, 3, 2, 1, 0).reshape(27, Cc, O).contiguous(), 8)    # [.., piece (mid,hi,lo), 4]
+    mid, hi, lo = pc[..., 0, :], pc[..., 1, :], pc[..., 2, :]
+    return torch.stack([hi, lo, hi, hi, mid, mid], -2).contiguous()        # the B operands {bh,bl} {bh,bh} {bm,bm}
+
+
+def conv3_split_(x: torch.Tensor, W3: torch.Tensor, shift: torch.Tensor, mode: int,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3x3 stride-1 'same' conv of channels_last_3d x with the fused epilogue, direct (implicit GEMM) on the bf16 matrix
+    pipe with exact three-piece splits; W3 = conv_weights_split(w)"""
+    lib = load()
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
+    O = int(W3.shape[3])
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
+        residual = residual.contiguous(memory_format=torch.channels_last_3d)
+    lib.sp3d_conv3_split.restype = C.c_int
+    lib.sp3d_conv3_split.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
+    check(lib.sp3d_conv3_split(x.data_ptr(), W3.data_ptr(), y.data_ptr(), shift.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
+                               _stream(x.device)), "sp3d_conv3_split")
+    return y
 
 
 def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,

@@ -856,6 +856,259 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Direct 3x3x3 convolution on the bf16 matrix pipe at fp32 accuracy (implicit GEMM, no Winograd).
+// With exact three-piece splits a multiply costs 3 bf16 MFMA slots, and the bf16 pipe is 16x the fp32 one: the 2.25x
+// multiplication saving of (x-folded) Winograd no longer pays for its operand transforms - the fused Winograd kernels
+// above are VALU-bound (183 VALU instructions per 18 MFMAs, every step re-transforms and re-splits its operands).  Here
+// an input value is split ONCE when its region is staged (pieces stored in LDS: 24 B per voxel and 4-channel group,
+// [lo hi mid]), the A operand of tap (dx,dy,dz) is the staged record of the shifted voxel - read with a compile-time LDS
+// offset, no VALU at all - and the accumulators ARE the outputs.  Per (tap, 32-voxel block): 3 LDS reads + 3 MFMAs
+//     {lo,hi} x {bh,bl}  +  {hi,mid} x {bh,bh}  +  {hi,mid} x {bm,bm}      (A quads are consecutive registers)
+// Block = 8x8x2 outputs (4 MFMA row blocks) x NB*32 output channels per wave, 8-channel chunks, region 10x10x4 voxels
+// = 19.2 KB of LDS.  Weights: per (tap, chunk, lane half, output) one 24-byte record [mid hi lo] (conv_weights_split).
+// ------------------------------------------------------------------------------------------
+// Workgroup = 4 consumer waves + 4 producer waves (one of each per SIMD), persistent over output blocks of 16x8x4 voxels.
+//   consumers (wave = z layer, 4 row blocks of 16x2 voxels x 32 outputs): per tap 8 ds_read_b128 + 3 global_load_dwordx4
+//     + 12 matrix instructions, nothing else; operands one tap ahead, weights three taps ahead (across chunk boundaries);
+//   producers: fetch the 18x10x6 region of the NEXT (block, 8-channel chunk) item, split it, write it to the other LDS
+//     buffer.  They are separate waves because vmcnt is in-order: a consumer that had the region loads of the next chunk
+//     in flight waited for them at its next weight wait (58 us of 207), and between workgroups nobody covered the first
+//     chunk's latency.  One barrier per item.
+// LDS per buffer: one plane per 4-channel group (lane half); a voxel is the two A operands ready to use, 8 dwords
+// [lo hi | hi mid]; row pitch 148 dwords: the 16 lanes of a ds_read_b128 group sit on 16 distinct 4-bank slots for row
+// blocks of 16(x) x 2(y) voxels (searched over pitches and block shapes; 4x8 blocks have no conflict-free pitch).
+constexpr int CD_BX = 16, CD_BY = 8, CD_BZ = 4;
+constexpr int CD_RX = CD_BX + 2, CD_RY = CD_BY + 2, CD_RZ = CD_BZ + 2, CD_VOX = 8, CD_ROW = 148;
+constexpr int CD_PLANE = CD_RZ * CD_RY * CD_ROW;                       // 8 880 dwords
+constexpr int CD_BUF = 2 * CD_PLANE;                                   // 17 760 dwords = 71 040 B per buffer
+constexpr int CD_NV4 = CD_RX * CD_RY * CD_RZ * 2;                      // float4 per item: 2 160
+constexpr int CD_PROD = 4;                                             // producer waves: one per SIMD
+constexpr int CD_PER = (CD_NV4 + 64 * CD_PROD - 1) / (64 * CD_PROD);   // 9 float4 per producer lane
+
+struct CdRec { u32x4 hl, hh, mm; };                                    // weight record: B operands {bh,bl} {bh,bh} {bm,bm}
+struct CdA { u32x4 lh[4], hm[4]; };                                    // A operands of the 4 row blocks: {lo,hi} {hi,mid}
+
+#ifdef SP3D_CD_TIMELINE
+__device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s_memtime stamps of workgroup 0
+#define CD_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (g_cd_tl && blockIdx.x == 0 && lane == 0 && item < 64) g_cd_tl[(wave * 64 + item) * 4 + (slot)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CD_STAMP(slot) do { } while (0)
+#endif
+
+template <int C, int MODE>
+__global__ __launch_bounds__(64 * (4 + CD_PROD)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict__ W3, float *__restrict__ y,
+                        const float *__restrict__ shift, const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
+                        int NBY, int NBZ, int nblocks)
+{
+    constexpr int O = 32, NCH = C / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUF dwords
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
+    const int my_blocks = ((int)blockIdx.x < nblocks) ? (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_items = my_blocks * NCH;
+    auto decode = [&](int item, int &b, int &ox0, int &oy0, int &oz0) {
+        int bid = (int)blockIdx.x + (item / NCH) * (int)gridDim.x;
+        const int bz = bid % NBZ; bid /= NBZ;
+        const int by = bid % NBY; bid /= NBY;
+        const int bx = bid % NBX;
+        b = bid / NBX;
+        ox0 = bx * CD_BX; oy0 = by * CD_BY; oz0 = bz * CD_BZ;
+    };
+
+    if (wave >= 4) {
+        // ---------------- producers: item k -> buffer k & 1 ----------------
+        const int pt = tid - 256;                                          // 0 .. 64*CD_PROD-1
+        // VALU issue on a SIMD goes to the older wave first: without priority the (younger) producers got the slots the
+        // consumer's matrix stream left over - 28 cycles per instruction, 14 k cycles per item against the consumers' 12 k
+        __builtin_amdgcn_s_setprio(2);
+        // the producers get one issue slot per consumer matrix instruction (324 per item): everything that does not depend
+        // on the item is computed once - LDS offset, offset inside the sample, region coordinates
+        float4 d[CD_PER];
+        int lo_[CD_PER], rel[CD_PER], vxyz[CD_PER];
+#pragma unroll
+        for (int u = 0; u < CD_PER; ++u) {
+            const int idx = pt + 64 * CD_PROD * u;
+            const int v = idx >> 1, half = idx & 1;
+            const int vx = v % CD_RX, vy = (v / CD_RX) % CD_RY, vz = v / (CD_RX * CD_RY);
+            lo_[u] = idx < CD_NV4 ? half * CD_PLANE + (vz * CD_RY + vy) * CD_ROW + vx * CD_VOX : -1;
+            rel[u] = ((vx * Y + vy) * Z + vz) * C + half * 4;
+            vxyz[u] = idx < CD_NV4 ? (vx | (vy << 8) | (vz << 16)) : 0x00ffffff;      // 255: never in range
+        }
+        auto issue = [&](int k) {                                          // loads of item k: in flight until iteration k
+            int b, ox0, oy0, oz0;
+            decode(k, b, ox0, oy0, oz0);
+            // element offset of region voxel (0,0,0), chunk k % NCH; may be negative at the volume border (never read there)
+            const float *xb = x + ((((int64_t)b * X + (ox0 - 1)) * Y + (oy0 - 1)) * Z + (oz0 - 1)) * C + (k % NCH) * 8;
+            // voxel (vx,vy,vz) is inside the volume iff vx in [xlo, xhi) ...: wave-uniform bounds
+            const int xlo = 1 - ox0, xhi = X + 1 - ox0, ylo = 1 - oy0, yhi = Y + 1 - oy0, zlo = 1 - oz0, zhi = Z + 1 - oz0;
+#pragma unroll
+            for (int u = 0; u < CD_PER; ++u) {
+                const int vx = vxyz[u] & 255, vy = (vxyz[u] >> 8) & 255, vz = vxyz[u] >> 16;
+                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (vx >= xlo && vx < xhi && vy >= ylo && vy < yhi && vz >= zlo && vz < zhi)
+                    d[u] = *reinterpret_cast<const float4 *>(xb + rel[u]);
+            }
+        };
+        if (n_items > 0) issue(0);
+        for (int k = 0; k <= n_items; ++k) {
+            if (k < n_items) {
+                { const int item = k; CD_STAMP(0); }
+                unsigned *buf = cd_lds + (k & 1) * CD_BUF;
+#ifdef SP3D_CD_TIMELINE
+                __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) lgkmcnt(0): separates the load wait from the split
+                { const int item = k; CD_STAMP(3); }      // (slot 3 is overwritten after the barrier for consumers only)
+#endif
+#pragma unroll
+                for (int u = 0; u < CD_PER; ++u) {
+                    // a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits); stored as the operands {lo,hi} and {hi,mid}
+                    const float4 a = d[u];
+                    const unsigned hi01 = pack_bf16(a.x, a.y), hi23 = pack_bf16(a.z, a.w);
+                    const float r0 = a.x - bf16_lo(hi01), r1 = a.y - bf16_hi(hi01), r2 = a.z - bf16_lo(hi23), r3 = a.w - bf16_hi(hi23);
+                    const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
+                    const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
+                    const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+                    if (lo_[u] >= 0) {
+                        unsigned *p = buf + lo_[u];
+                        *reinterpret_cast<u32x4 *>(p) = u32x4{lo01, lo23, hi01, hi23};
+                        *reinterpret_cast<u32x4 *>(p + 4) = u32x4{hi01, hi23, mid01, mid23};
+                    }
+                }
+                { const int item = k; CD_STAMP(1); }
+                if (k + 1 < n_items) issue(k + 1);                         // one item ahead: its latency hides behind the barrier
+            }
+            if (k < n_items) { const int item = k; CD_STAMP(2); }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- consumers: item k - 1 from buffer (k - 1) & 1 ----------------
+    // A operands of row block mb: voxel (x = t & 15, y = (t >> 4) + 2 mb, z = wave) + tap offset
+    const int a_off = h * CD_PLANE + (wave * CD_RY + (t >> 4)) * CD_ROW + (t & 15) * CD_VOX;
+    // weight record of (tap, chunk, lane half h, output t): 12 dwords
+    const unsigned *wl = W3 + ((int64_t)h * O + t) * 12;
+    auto load_w = [&](int q) {                         // q = flattened (item, tap) index; weights depend on (chunk, tap) only
+        const int cc = (q / 27) % NCH, tap = q % 27;
+        const unsigned *r = wl + ((int64_t)tap * NCH + cc) * 2 * O * 12;
+        CdRec w;
+        w.hl = *reinterpret_cast<const u32x4 *>(r);
+        w.hh = *reinterpret_cast<const u32x4 *>(r + 4);
+        w.mm = *reinterpret_cast<const u32x4 *>(r + 8);
+        return w;
+    };
+    f32x16 acc[4];
+    CdRec w0, w1, w2, w3;                              // weights of flattened tap q .. q+3
+    if (n_items > 0) { w0 = load_w(0); w1 = load_w(1); w2 = load_w(2); }
+    __syncthreads();                                   // item 0 staged
+    for (int k = 1; k <= n_items; ++k) {
+        const int item = k - 1, cc = item % NCH;
+        const unsigned *ab = cd_lds + (item & 1) * CD_BUF + a_off;
+        if (cc == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+        }
+        auto load_a = [&](int tap, CdA &a) {
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const unsigned *p = ab + (dz * CD_RY + 2 * mb + dy) * CD_ROW + dx * CD_VOX;
+                a.lh[mb] = *reinterpret_cast<const u32x4 *>(p);
+                a.hm[mb] = *reinterpret_cast<const u32x4 *>(p + 4);
+            }
+        };
+        CdA a0, a1;
+        load_a(0, a0);
+        const int q0 = item * 27;
+        CD_STAMP(0);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            __builtin_amdgcn_sched_barrier(0);
+            w3 = load_w(min(q0 + tap + 3, n_items * 27 - 1));          // unconditional: a branch here costs the register renaming
+            if (tap + 1 < 27) load_a(tap + 1, a1);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.lh[mb], w0.hl, acc[mb]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.hm[mb], w0.hh, acc[mb]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.hm[mb], w0.mm, acc[mb]);
+            // issue order: one load between matrix instructions.  Eight ds_read_b128 in a row from four waves at once fill the
+            // LDS queue, and a wave blocked on LDS issue cannot issue its matrix instructions either (in-order): the
+            // matrix pipe idled ~240 of 650 cycles per tap (tools/conv3_timeline.py)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1;
+            w0 = w1; w1 = w2; w2 = w3;
+        }
+        CD_STAMP(1);
+        if (cc == NCH - 1) {
+            // D of the 32x32 MFMA: lane (col = t, h) holds rows m = 8 (v >> 2) + (v & 3) + 4 h, v = 0..15; row m of row block
+            // mb is voxel (x = m & 15, y = (m >> 4) + 2 mb, z = wave) -> x = 8 ((v >> 2) & 1) + 4 h + (v & 3), y = (v >> 3) + 2 mb
+            int b, ox0, oy0, oz0;
+            decode(item, b, ox0, oy0, oz0);
+            const int xl = ox0 + 4 * h, zl = oz0 + wave;
+            const int64_t obase = ((((int64_t)b * X + xl) * Y + oy0) * Z + zl) * O + t;
+            const float sh = shift[t];
+            auto emit = [&](int mb, int v, int64_t idx) {
+                float val = acc[mb][v] + sh;
+                if (MODE == 2) val += res[idx];
+                if (MODE >= 1) val = fmaxf(val, 0.0f);
+                if (MODE == 3) val += res[idx];
+#if SP3D_W16_ABLATE & 16
+                if (val == 123.456f)
+#endif
+                y[idx] = val;
+            };
+            if (zl < Z) {
+                if (ox0 + CD_BX <= X && oy0 + CD_BY <= Y) {      // interior block: straight-line stores (64 guarded stores
+#pragma unroll                                                   // became 64 out-of-line branch targets: 13 k cycles)
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+                            emit(mb, v, obase + ((int64_t)(8 * ((v >> 2) & 1) + (v & 3)) * Y + (v >> 3) + 2 * mb) * Z * O);
+                } else {
+#pragma unroll 1
+                    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll 1
+                        for (int v = 0; v < 16; ++v) {
+                            const int dx = 8 * ((v >> 2) & 1) + (v & 3), dy = (v >> 3) + 2 * mb;
+                            float av = 0.0f;                     // acc[mb][v] with run-time indices: select, no scratch
+#pragma unroll
+                            for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+                                for (int v2 = 0; v2 < 16; ++v2) av = (m2 == mb && v2 == v) ? acc[m2][v2] : av;
+                            if (xl + dx < X && oy0 + dy < Y) {
+                                const int64_t idx = obase + ((int64_t)dx * Y + dy) * Z * O;
+                                float val = av + sh;
+                                if (MODE == 2) val += res[idx];
+                                if (MODE >= 1) val = fmaxf(val, 0.0f);
+                                if (MODE == 3) val += res[idx];
+                                y[idx] = val;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        CD_STAMP(2);
+        __syncthreads();
+        CD_STAMP(3);
+    }
+}
+
 } // namespace sp3d
 
 extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
@@ -951,4 +1204,48 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
 #undef SP3D_WF
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,
+                                int B, int X, int Y, int Z, int C, int O, void *stream)
+{
+    using namespace sp3d;
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
+    if (!x || !W3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if (O != 32 || (C != 16 && C != 32) || (reinterpret_cast<uintptr_t>(W3) & 15)) return SP3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * C > 0x7fffffff) return SP3D_ERANGE;
+    const int NBX = (X + CD_BX - 1) / CD_BX, NBY = (Y + CD_BY - 1) / CD_BY, NBZ = (Z + CD_BZ - 1) / CD_BZ;
+    const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
+    if (blocks > 0x7fffffff) return SP3D_ERANGE;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    // persistent workgroups, one per CU (142 KB of LDS each), an equal number of blocks each
+    const int rounds = (int)((blocks + cus - 1) / cus);
+    const int nwg = (int)((blocks + rounds - 1) / rounds);
+    const dim3 grid((unsigned)nwg), block(64 * (4 + CD_PROD));
+    const size_t lds = (size_t)2 * CD_BUF * sizeof(unsigned);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3);
+#define SP3D_CD(C_, M_) { static bool attr = false; if (!attr) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
+    hipLaunchKernelGGL((conv3_split_kernel<C_, M_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks); }
+#define SP3D_CDM(C_) switch (mode) { case 0: SP3D_CD(C_, 0); break; case 1: SP3D_CD(C_, 1); break; case 2: SP3D_CD(C_, 2); break; default: SP3D_CD(C_, 3); }
+    if (C == 16) { SP3D_CDM(16) } else { SP3D_CDM(32) }
+#undef SP3D_CDM
+#undef SP3D_CD
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_debug_conv3_timeline(void *dev_buffer)
+{
+#ifdef SP3D_CD_TIMELINE
+    unsigned long long *p = (unsigned long long *)dev_buffer;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sp3d::g_cd_tl), &p, sizeof(p));
+#else
+    (void)dev_buffer;
+    return SP3D_EUNSUPPORTED;
+#endif
 }

@@ -227,6 +227,10 @@ class _FoldedV2V:
                                             (w.shape[0] == 64 and w.shape[1] == 32))
             u1 = _lib.wino_weights(w1) if wino(w1) else None
             u2 = _lib.wino_weights(w2) if wino(w2) else None
+            # full-resolution layers (16 | 32 -> 32): direct convolution on the bf16 matrix pipe (three exact pieces)
+            for wc, u in ((w1, u1), (w2, u2)):
+                if u is not None and wc.shape[0] == 32 and wc.shape[1] in (16, 32):
+                    u._sp3d_direct = _lib.conv_weights_split(wc)
             for u in (u1, u2):                 # layers of the fused kernels: weights split for the bf16 matrix pipe
                 if u is not None and u.shape[2] == 32 and u.shape[1] in (16, 32):
                     u._sp3d_split = _lib.wino_weights_split(u)
@@ -267,6 +271,11 @@ class _FoldedV2V:
                 return _lib.wino_fused_conv3d_(x, u, shift, mode, residual, u3)
             if C >= 128 or (C >= 64 and 64 * T * C * 4 <= 160e6):
                 return _lib.wino_conv3d_(x, u, shift, mode, residual)
+            w3 = getattr(u, "_sp3d_direct", None) if getattr(self.net, "wino_split", True) and getattr(self.net, "direct_conv", True) else None
+            if w3 is not None and C in (16, 32) and u.shape[2] == 32:
+                # implicit GEMM with exact three-piece bf16 splits: no Winograd transforms (which made the fused kernel
+                # VALU-bound); 155 vs 163 us (ReLU), 159 vs 182 us (residual) at (4,32,80,80,20)
+                return _lib.conv3_split_(x, w3, shift, mode, residual)
             if C in (16, 32) and u.shape[2] == 32:
                 # full-resolution layers: the transformed tensor would be hundreds of MB, so everything (transforms,
                 # v_mfma_f32_32x32x2_f32 products, epilogue) happens in one kernel: 225 us instead of 345 us at
@@ -508,6 +517,7 @@ class V2VNet(nn.Module):
         self.winograd = True             # ... and whose wide low-resolution 3x3x3 convs run as Winograd F(2,3)
         self.zdft = True                 # ... root grid: direct z-DFTs + dense 2-D transforms instead of the 3-D real plans
         self.wino_split = True           # ... fused Winograd layers: exact 3-piece bf16 splits on the bf16 matrix pipe
+        self.direct_conv = True          # ... full-resolution 3x3x3 layers: direct (implicit GEMM) split convolution
         self._plan = None
         self.reset_parameters()
 

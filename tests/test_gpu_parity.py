@@ -1052,3 +1052,39 @@ def test_winograd_fused_split64_kernel(shape):
     e, e3 = float((y.double() - ref).abs().max()), float((three.double() - ref).abs().max())
     assert e <= 5e-5 * max(1.0, float(ref.abs().max()))
     assert e <= 1.5 * e3 + 1e-7, (e, e3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 32, 32, (16, 12, 8), 1), (1, 16, 32, (9, 7, 5), 2), (1, 32, 32, (8, 8, 2), 3),
+                                   (2, 16, 32, (24, 8, 6), 0), (3, 32, 32, (40, 40, 10), 2), (1, 32, 32, (80, 80, 20), 1)])
+def test_direct_conv3_split_kernel(shape):
+    """sp3d_conv3_split (implicit GEMM, three exact bf16 pieces per operand, no Winograd) == conv3d + epilogue against a
+    float64 referee, at least as close as MIOpen's fp32 convolution; block-edge and odd sizes included"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    B, C, O, (X, Y, Z), mode = shape
+    g = torch.Generator(device="cpu").manual_seed(29)
+    x = (torch.randn((B, C, X, Y, Z), generator=g) * 2.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((O, C, 3, 3, 3), generator=g) * 0.05).cuda()
+    shift = torch.randn((O,), generator=g).cuda()
+    res = torch.randn((B, O, X, Y, Z), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    W3 = _lib.conv_weights_split(w)
+    back = ((W3[..., 0, :].float() + W3[..., 4, :].float()) + W3[..., 1, :].float()).permute(0, 1, 2, 4, 3).reshape(27, C, O)
+    assert torch.equal(back, w.permute(4, 3, 2, 1, 0).reshape(27, C, O))       # hi + lo + mid reproduce the weights exactly
+
+    def epi(c, dt):
+        c = c + shift.to(dt).view(1, O, 1, 1, 1)
+        if mode == 2:
+            c = c + res.to(dt)
+        if mode >= 1:
+            c = c.clamp_min(0)
+        if mode == 3:
+            c = c + res.to(dt)
+        return c
+    ref = epi(F.conv3d(x.double(), w.double(), padding=1), torch.float64)
+    lib32 = epi(F.conv3d(x, w, padding=1), torch.float32)
+    y = _lib.conv3_split_(x, W3, shift, mode, res if mode >= 2 else None)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last_3d)
+    e, e32 = float((y.double() - ref).abs().max()), float((lib32.double() - ref).abs().max())
+    assert e <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert e <= 1.5 * e32 + 1e-6, (e, e32)

@@ -7,7 +7,7 @@
 import ctypes, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 MASKS = {"full": 0, "no_mfma": 1, "no_weight_loads": 2, "no_split": 4, "no_lds_reads": 8,
-         "no_mfma_no_split": 5, "no_mfma_no_loads_no_lds": 11, "staging_epilogue_valu_only": 15}
+         "no_mfma_no_split": 5, "no_mfma_no_loads_no_lds": 11, "staging_epilogue_valu_only": 15, "mfma_only": 14}
 LIBDIR = os.path.join(ROOT, "selfpose3d_amd", "ablate")
 
 
@@ -30,6 +30,33 @@ if "--build-only" in sys.argv:
     sys.exit(0)
 import torch
 from selfpose3d_amd import _lib
+if "--direct" in sys.argv:         # the direct convolution kernel: 1 no MFMA, 2 no weight loads, 4 no region loads, 8 no LDS reads
+    B, C, X, Y, Z = 4, 32, 80, 80, 20
+    x = torch.randn(B, C, X, Y, Z).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(32, C, 3, 3, 3) * 0.05).cuda()
+    W3 = _lib.conv_weights_split(w)
+    shift = torch.randn(32).cuda()
+    y = torch.empty(B, X, Y, Z, 32, device="cuda")
+    out = {}
+    for name, m in {"full": 0, "no_mfma": 1, "no_weight_loads": 2, "no_region_loads": 4, "no_lds_reads": 8,
+                    "mfma_only": 14, "nothing": 15}.items():
+        L = ctypes.CDLL(lib_path(m))
+        f = L.sp3d_conv3_split
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        run = lambda: f(x.data_ptr(), W3.data_ptr(), y.data_ptr(), shift.data_ptr(), None, 1, B, X, Y, Z, C, 32, None)
+        for _ in range(3):
+            assert run() == 0
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 if "--full-res" in sys.argv:       # the full-resolution kernel (wino_fused3_kernel) under the same switches
     B, C, X, Y, Z = 4, 32, 80, 80, 20
     x = torch.randn(B, C, X, Y, Z).cuda().contiguous(memory_format=torch.channels_last_3d)

@@ -32,8 +32,10 @@ for name, (B, C, X, Y, Z, mode) in {} if "--half" in sys.argv else {"root_32_rel
     res = torch.randn(B, 32, X, Y, Z, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d) if mode >= 2 else None
     U = _lib.wino_weights(w)
     U3 = _lib.wino_weights_split(U)
+    W3 = _lib.conv_weights_split(w)
     r = {"fp32_mfma_us": timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res)),
-         "bf16x3_us": timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3))}
+         "bf16x3_us": timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3)),
+         "direct_bf16x3_us": timeit(lambda: _lib.conv3_split_(x, W3, shift, mode, res))}
     if B * X * Y * Z <= 600000:
         ref = F.conv3d(x[:1].double(), w.double(), padding=1) + shift.double().view(1, 32, 1, 1, 1)
         if mode == 2:
@@ -45,6 +47,8 @@ for name, (B, C, X, Y, Z, mode) in {} if "--half" in sys.argv else {"root_32_rel
         if mode == 2:
             d = d + res[:1]
         d = d.clamp_min(0).double()
+        yd = _lib.conv3_split_(x, W3, shift, mode, res)[:1].double()
+        r.update(max_err_direct_bf16x3=float((yd - ref).abs().max()))
         r.update(max_err_fp32_mfma=float((y32 - ref).abs().max()), max_err_bf16x3=float((y3 - ref).abs().max()),
                  max_err_direct_fp32_conv=float((d - ref).abs().max()), ref_max=float(ref.abs().max()))
     out[name] = r
@@ -58,7 +62,7 @@ for name, (B, C, X, Y, Z, mode) in {"half_64_res": (4, 64, 40, 40, 10, 2), "half
     U = _lib.wino_weights(w)
     U3 = _lib.wino_weights_split(U, 16)
     r = {}
-    for nbw, ks in ((1, 1), (2, 1), (4, 1), (2, 2), (4, 2)):
+    for nbw, ks in ((2, 2),):
         _lib.load().sp3d_debug_set_w16_nbw(nbw, ks)
         r[f"fused_bf16x3_nbw{nbw}_ks{ks}_us"] = timeit(lambda: _lib.wino_fused_conv3d_(x, U, shift, mode, res, U3))
     _lib.load().sp3d_debug_set_w16_nbw(0, 1)

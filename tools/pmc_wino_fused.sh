@@ -15,6 +15,6 @@ cd $R; python tools/pmc_summary.py $OUT > $OUT/summary.json 2>/dev/null; python 
 import json
 d=json.load(open("$OUT/summary.json"))
 for k,v in d.items():
-    if "wino_fused" in k:
+    if "wino_fused" in k or "conv3_split" in k:
         for c,x in sorted(v.items()): print("%-32s %16.1f"%(c,x["mean"]))
 PY
