@@ -337,6 +337,13 @@ int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const floa
 int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode, int B,
                      int X, int Y, int Z, int C, int O, void *stream);
 
+/* The same with split ("S3") activations between consecutive layers: an S3 tensor is (B,X,Y,Z,C/4, 8 dwords), per voxel and
+ * 4-channel group the two A operands [lo hi | hi mid] (bf16 pairs) of the three exact pieces of each fp32 value.
+ * xs != NULL (C = 32): the input is read pre-split (x may be NULL); ys != NULL (modes 1, 2): the result is ALSO (y != NULL) or
+ * ONLY (y == NULL) written as an S3 tensor for the next layer, whose loader waves then only copy.  16-byte aligned. */
+int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
+                        const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream);
+
 /*
  * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
  * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -605,25 +605,40 @@ def conv_weights_split(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo, hi, hi, mid, mid], -2).contiguous()        # the B operands {bh,bl} {bh,bh} {bm,bm}
 
 
-def conv3_split_(x: torch.Tensor, W3: torch.Tensor, shift: torch.Tensor, mode: int,
-                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def conv3_split_(x: Optional[torch.Tensor], W3: torch.Tensor, shift: torch.Tensor, mode: int,
+                 residual: Optional[torch.Tensor] = None, x_s3: Optional[torch.Tensor] = None, want_f32: bool = True,
+                 want_s3: bool = False):
     """3x3x3 stride-1 'same' conv of channels_last_3d x with the fused epilogue, direct (implicit GEMM) on the bf16 matrix
-    pipe with exact three-piece splits; W3 = conv_weights_split(w)"""
+    pipe with exact three-piece splits; W3 = conv_weights_split(w).  x_s3: the input as an S3 tensor (B,X,Y,Z,C/4,8) int32
+    written by the previous layer (x may then be None); want_s3: also return the result as an S3 tensor.
+    Returns y, or (y | None, y_s3) when want_s3."""
     lib = load()
-    _require_cuda(x, "x")
-    B, Cc, X, Y, Z = (int(v) for v in x.shape)
-    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
-        raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
+    src = x if x is not None else x_s3
+    _require_cuda(src, "x")
+    if x_s3 is not None:
+        B, X, Y, Z, G, _ = (int(v) for v in x_s3.shape)
+        Cc = 4 * G
+        if x_s3.dtype != torch.int32 or not x_s3.is_contiguous():
+            raise Sp3dError("conv3_split_: x_s3 must be a dense int32 (B,X,Y,Z,C/4,8) tensor")
+    else:
+        B, Cc, X, Y, Z = (int(v) for v in x.shape)
+        if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+            raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
     O = int(W3.shape[3])
-    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
-    if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
+    dev = src.device
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3) if want_f32 else None
+    ys = torch.empty((B, X, Y, Z, O // 4, 8), dtype=torch.int32, device=dev) if want_s3 else None
+    if residual is not None and (tuple(residual.shape) != (B, O, X, Y, Z) or
+                                 not residual.is_contiguous(memory_format=torch.channels_last_3d)):
         residual = residual.contiguous(memory_format=torch.channels_last_3d)
-    lib.sp3d_conv3_split.restype = C.c_int
-    lib.sp3d_conv3_split.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
-    check(lib.sp3d_conv3_split(x.data_ptr(), W3.data_ptr(), y.data_ptr(), shift.data_ptr(),
-                               residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
-                               _stream(x.device)), "sp3d_conv3_split")
-    return y
+    lib.sp3d_conv3_split_ex.restype = C.c_int
+    lib.sp3d_conv3_split_ex.argtypes = [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]
+    check(lib.sp3d_conv3_split_ex(x.data_ptr() if (x is not None and x_s3 is None) else None,
+                                  x_s3.data_ptr() if x_s3 is not None else None, W3.data_ptr(),
+                                  y.data_ptr() if y is not None else None, ys.data_ptr() if ys is not None else None,
+                                  shift.data_ptr(), residual.data_ptr() if residual is not None else None, int(mode),
+                                  B, X, Y, Z, Cc, O, _stream(dev)), "sp3d_conv3_split_ex")
+    return (y, ys) if want_s3 else y
 
 
 def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,

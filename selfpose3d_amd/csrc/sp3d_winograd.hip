@@ -877,18 +877,21 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
 //     in flight waited for them at its next weight wait (58 us of 207), and between workgroups nobody covered the first
 //     chunk's latency.  One barrier per item.
 // LDS per buffer: one plane per 4-channel group (lane half); a voxel is the two A operands ready to use, 8 dwords
-// [lo hi | hi mid]; row pitch 148 dwords: the 16 lanes of a ds_read_b128 group sit on 16 distinct 4-bank slots for row
-// blocks of 16(x) x 2(y) voxels (searched over pitches and block shapes; 4x8 blocks have no conflict-free pitch).
+// [lo hi | hi mid]; rows of 18 voxels (144 dwords), z planes of 10 rows + 4 dwords: with lane = (y = t & 7, z = t >> 3) the
+// 16 lanes of a ds_read_b128 group sit on 16 distinct 4-bank slots (searched over row / plane pitches).
+// A consumer wave owns 4 consecutive x of the block and ALL its (y,z): the operand of region voxel x' serves the taps
+// dx = x' - x of every x it owns, so a (dy,dz) step reads 6 operands for 36 matrix instructions instead of 12 - the LDS
+// (85 of its 128 B/clk with one operand read per tap and row block) was what the matrix pipe and the loader waves waited on.
 constexpr int CD_BX = 16, CD_BY = 8, CD_BZ = 4;
-constexpr int CD_RX = CD_BX + 2, CD_RY = CD_BY + 2, CD_RZ = CD_BZ + 2, CD_VOX = 8, CD_ROW = 148;
-constexpr int CD_PLANE = CD_RZ * CD_RY * CD_ROW;                       // 8 880 dwords
-constexpr int CD_BUF = 2 * CD_PLANE;                                   // 17 760 dwords = 71 040 B per buffer
+constexpr int CD_RX = CD_BX + 2, CD_RY = CD_BY + 2, CD_RZ = CD_BZ + 2, CD_VOX = 8, CD_ROW = CD_RX * CD_VOX, CD_ZP = CD_RY * CD_ROW + 4;
+constexpr int CD_PLANE = CD_RZ * CD_ZP;                                // 8 664 dwords
+constexpr int CD_BUF = 2 * CD_PLANE;                                   // 17 328 dwords = 69 312 B per buffer
 constexpr int CD_NV4 = CD_RX * CD_RY * CD_RZ * 2;                      // float4 per item: 2 160
 constexpr int CD_PROD = 4;                                             // producer waves: one per SIMD
 constexpr int CD_PER = (CD_NV4 + 64 * CD_PROD - 1) / (64 * CD_PROD);   // 9 float4 per producer lane
 
 struct CdRec { u32x4 hl, hh, mm; };                                    // weight record: B operands {bh,bl} {bh,bh} {bm,bm}
-struct CdA { u32x4 lh[4], hm[4]; };                                    // A operands of the 4 row blocks: {lo,hi} {hi,mid}
+
 
 #ifdef SP3D_CD_TIMELINE
 __device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s_memtime stamps of workgroup 0
@@ -897,14 +900,32 @@ __device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s
 #define CD_STAMP(slot) do { } while (0)
 #endif
 
-template <int C, int MODE>
+// a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits), as the two A operands {lo,hi} and {hi,mid} of 4 channels
+__device__ __forceinline__ void split3(const float4 a, u32x4 &q0, u32x4 &q1)
+{
+    const unsigned hi01 = pack_bf16(a.x, a.y), hi23 = pack_bf16(a.z, a.w);
+    const float r0 = a.x - bf16_lo(hi01), r1 = a.y - bf16_hi(hi01), r2 = a.z - bf16_lo(hi23), r3 = a.w - bf16_hi(hi23);
+    const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
+    const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
+    const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
+    q0 = u32x4{lo01, lo23, hi01, hi23};
+    q1 = u32x4{hi01, hi23, mid01, mid23};
+}
+
+// IN_S3: the input arrives already split ("S3" tensor (B,X,Y,Z,C/4,8 dwords): per voxel and 4-channel group the two A
+// operands [lo hi | hi mid], written by the previous layer's epilogue) - the producers then only copy, 4 instructions per
+// 32 bytes.  They get ONE issue slot per consumer matrix instruction (a co-resident wave's VALU only issues between the
+// matrix instructions: measured 58 cycles per producer instruction), so splitting in the producers (216 VALU per item)
+// made them the pole: 17 k cycles per item against the consumers' 12 k.
+// OUT: 1 fp32 channels-last result, 2 split result (S3) for the next layer, 3 both.
+template <int C, int MODE, bool IN_S3, int OUT>
 __global__ __launch_bounds__(64 * (4 + CD_PROD)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict__ W3, float *__restrict__ y,
                         const float *__restrict__ shift, const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
-                        int NBY, int NBZ, int nblocks)
+                        int NBY, int NBZ, int nblocks, const unsigned *__restrict__ xs, unsigned *__restrict__ ys)
 {
     constexpr int O = 32, NCH = C / 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUF dwords
+    extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUF dwords + 4 x 1024 floats of scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
     const int my_blocks = ((int)blockIdx.x < nblocks) ? (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int n_items = my_blocks * NCH;
@@ -922,33 +943,47 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
         const int pt = tid - 256;                                          // 0 .. 64*CD_PROD-1
         // VALU issue on a SIMD goes to the older wave first: without priority the (younger) producers got the slots the
         // consumer's matrix stream left over - 28 cycles per instruction, 14 k cycles per item against the consumers' 12 k
-        __builtin_amdgcn_s_setprio(2);
+        if (!IN_S3) __builtin_amdgcn_s_setprio(2);        // (copy-only loaders fit into the leftover slots: raising them costs
+                                                          // the consumers more than it gains, 15 k vs 11.6 k cycles per item)
         // the producers get one issue slot per consumer matrix instruction (324 per item): everything that does not depend
         // on the item is computed once - LDS offset, offset inside the sample, region coordinates
         float4 d[CD_PER];
+        u32x4 e0[IN_S3 ? CD_PER : 1], e1[IN_S3 ? CD_PER : 1];
         int lo_[CD_PER], rel[CD_PER], vxyz[CD_PER];
 #pragma unroll
         for (int u = 0; u < CD_PER; ++u) {
             const int idx = pt + 64 * CD_PROD * u;
             const int v = idx >> 1, half = idx & 1;
             const int vx = v % CD_RX, vy = (v / CD_RX) % CD_RY, vz = v / (CD_RX * CD_RY);
-            lo_[u] = idx < CD_NV4 ? half * CD_PLANE + (vz * CD_RY + vy) * CD_ROW + vx * CD_VOX : -1;
-            rel[u] = ((vx * Y + vy) * Z + vz) * C + half * 4;
+            lo_[u] = idx < CD_NV4 ? half * CD_PLANE + vz * CD_ZP + vy * CD_ROW + vx * CD_VOX : -1;
+            // fp32 input: C floats per voxel; S3 input: C/4 records of 8 dwords = 2 C dwords per voxel
+            rel[u] = IN_S3 ? ((vx * Y + vy) * Z + vz) * 2 * C + half * 8 : ((vx * Y + vy) * Z + vz) * C + half * 4;
             vxyz[u] = idx < CD_NV4 ? (vx | (vy << 8) | (vz << 16)) : 0x00ffffff;      // 255: never in range
         }
         auto issue = [&](int k) {                                          // loads of item k: in flight until iteration k
             int b, ox0, oy0, oz0;
             decode(k, b, ox0, oy0, oz0);
             // element offset of region voxel (0,0,0), chunk k % NCH; may be negative at the volume border (never read there)
-            const float *xb = x + ((((int64_t)b * X + (ox0 - 1)) * Y + (oy0 - 1)) * Z + (oz0 - 1)) * C + (k % NCH) * 8;
+            const int64_t vox0 = (((int64_t)b * X + (ox0 - 1)) * Y + (oy0 - 1)) * Z + (oz0 - 1);
+            const float *xb = x + vox0 * C + (k % NCH) * 8;
+            const unsigned *sb = xs + vox0 * 2 * C + (k % NCH) * 16;
             // voxel (vx,vy,vz) is inside the volume iff vx in [xlo, xhi) ...: wave-uniform bounds
             const int xlo = 1 - ox0, xhi = X + 1 - ox0, ylo = 1 - oy0, yhi = Y + 1 - oy0, zlo = 1 - oz0, zhi = Z + 1 - oz0;
 #pragma unroll
             for (int u = 0; u < CD_PER; ++u) {
                 const int vx = vxyz[u] & 255, vy = (vxyz[u] >> 8) & 255, vz = vxyz[u] >> 16;
-                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (vx >= xlo && vx < xhi && vy >= ylo && vy < yhi && vz >= zlo && vz < zhi)
-                    d[u] = *reinterpret_cast<const float4 *>(xb + rel[u]);
+                const bool in = vx >= xlo && vx < xhi && vy >= ylo && vy < yhi && vz >= zlo && vz < zhi;
+                if (IN_S3) {
+                    e0[u] = u32x4{0u, 0u, 0u, 0u};
+                    e1[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (in) {
+                        e0[u] = *reinterpret_cast<const u32x4 *>(sb + rel[u]);
+                        e1[u] = *reinterpret_cast<const u32x4 *>(sb + rel[u] + 4);
+                    }
+                } else {
+                    d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (in) d[u] = *reinterpret_cast<const float4 *>(xb + rel[u]);
+                }
             }
         };
         if (n_items > 0) issue(0);
@@ -962,17 +997,20 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #endif
 #pragma unroll
                 for (int u = 0; u < CD_PER; ++u) {
-                    // a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits); stored as the operands {lo,hi} and {hi,mid}
-                    const float4 a = d[u];
-                    const unsigned hi01 = pack_bf16(a.x, a.y), hi23 = pack_bf16(a.z, a.w);
-                    const float r0 = a.x - bf16_lo(hi01), r1 = a.y - bf16_hi(hi01), r2 = a.z - bf16_lo(hi23), r3 = a.w - bf16_hi(hi23);
-                    const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
-                    const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
-                    const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
-                    if (lo_[u] >= 0) {
-                        unsigned *p = buf + lo_[u];
-                        *reinterpret_cast<u32x4 *>(p) = u32x4{lo01, lo23, hi01, hi23};
-                        *reinterpret_cast<u32x4 *>(p + 4) = u32x4{hi01, hi23, mid01, mid23};
+                    if (IN_S3) {
+                        if (lo_[u] >= 0) {
+                            unsigned *p = buf + lo_[u];
+                            *reinterpret_cast<u32x4 *>(p) = e0[u];
+                            *reinterpret_cast<u32x4 *>(p + 4) = e1[u];
+                        }
+                    } else {
+                        u32x4 q0, q1;
+                        split3(d[u], q0, q1);
+                        if (lo_[u] >= 0) {
+                            unsigned *p = buf + lo_[u];
+                            *reinterpret_cast<u32x4 *>(p) = q0;
+                            *reinterpret_cast<u32x4 *>(p + 4) = q1;
+                        }
                     }
                 }
                 { const int item = k; CD_STAMP(1); }
@@ -985,22 +1023,28 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     }
 
     // ---------------- consumers: item k - 1 from buffer (k - 1) & 1 ----------------
-    // A operands of row block mb: voxel (x = t & 15, y = (t >> 4) + 2 mb, z = wave) + tap offset
-    const int a_off = h * CD_PLANE + (wave * CD_RY + (t >> 4)) * CD_ROW + (t & 15) * CD_VOX;
+    // lane (t, h): output voxels (x = 4 wave + i, y = t & 7, z = t >> 3), i = 0..3 (one accumulator each); operand j = 0..5
+    // of step (dy,dz) is region voxel (4 wave + j, y + dy, z + dz), channel group h
+    const int a_off = h * CD_PLANE + (t >> 3) * CD_ZP + (t & 7) * CD_ROW + 4 * wave * CD_VOX;
     // weight record of (tap, chunk, lane half h, output t): 12 dwords
     const unsigned *wl = W3 + ((int64_t)h * O + t) * 12;
-    auto load_w = [&](int q) {                         // q = flattened (item, tap) index; weights depend on (chunk, tap) only
-        const int cc = (q / 27) % NCH, tap = q % 27;
-        const unsigned *r = wl + ((int64_t)tap * NCH + cc) * 2 * O * 12;
-        CdRec w;
-        w.hl = *reinterpret_cast<const u32x4 *>(r);
-        w.hh = *reinterpret_cast<const u32x4 *>(r + 4);
-        w.mm = *reinterpret_cast<const u32x4 *>(r + 8);
+    struct W3Rec { CdRec d[3]; };                      // the three dx taps of one (dy,dz) step
+    auto load_w = [&](int q) {                         // q = flattened (item, step) index; weights depend on (chunk, step)
+        const int cc = (q / 9) % NCH, st = q % 9;
+        const unsigned *r = wl + ((int64_t)(3 * st) * NCH + cc) * 2 * O * 12;
+        W3Rec w;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            w.d[dx].hl = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12);
+            w.d[dx].hh = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12 + 4);
+            w.d[dx].mm = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12 + 8);
+        }
         return w;
     };
+    struct Opnd { u32x4 lh[6], hm[6]; };
     f32x16 acc[4];
-    CdRec w0, w1, w2, w3;                              // weights of flattened tap q .. q+3
-    if (n_items > 0) { w0 = load_w(0); w1 = load_w(1); w2 = load_w(2); }
+    W3Rec w0, w1;                                      // weights of flattened step q, q+1
+    if (n_items > 0) w0 = load_w(0);
     __syncthreads();                                   // item 0 staged
     for (int k = 1; k <= n_items; ++k) {
         const int item = k - 1, cc = item % NCH;
@@ -1011,96 +1055,97 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
         }
-        auto load_a = [&](int tap, CdA &a) {
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        auto load_a = [&](int st, Opnd &a) {
+            const int dz = st / 3, dy = st % 3;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const unsigned *p = ab + (dz * CD_RY + 2 * mb + dy) * CD_ROW + dx * CD_VOX;
-                a.lh[mb] = *reinterpret_cast<const u32x4 *>(p);
-                a.hm[mb] = *reinterpret_cast<const u32x4 *>(p + 4);
+            for (int j = 0; j < 6; ++j) {
+                const unsigned *p = ab + dz * CD_ZP + dy * CD_ROW + j * CD_VOX;
+                a.lh[j] = *reinterpret_cast<const u32x4 *>(p);
+                a.hm[j] = *reinterpret_cast<const u32x4 *>(p + 4);
             }
         };
-        CdA a0, a1;
+        Opnd a0, a1;
         load_a(0, a0);
-        const int q0 = item * 27;
+        const int q0 = item * 9;
         CD_STAMP(0);
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int st = 0; st < 9; ++st) {
             __builtin_amdgcn_sched_barrier(0);
-            w3 = load_w(min(q0 + tap + 3, n_items * 27 - 1));          // unconditional: a branch here costs the register renaming
-            if (tap + 1 < 27) load_a(tap + 1, a1);
+            w1 = load_w(min(q0 + st + 1, n_items * 9 - 1));             // unconditional: a branch here costs the register renaming
+            if (st + 1 < 9) load_a(st + 1, a1);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.lh[mb], w0.hl, acc[mb]);
+            for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.hm[mb], w0.hh, acc[mb]);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.lh[i + dx], w0.d[dx].hl, acc[i]);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma_bf16(a0.hm[mb], w0.mm, acc[mb]);
-            // issue order: one load between matrix instructions.  Eight ds_read_b128 in a row from four waves at once fill the
-            // LDS queue, and a wave blocked on LDS issue cannot issue its matrix instructions either (in-order): the
-            // matrix pipe idled ~240 of 650 cycles per tap (tools/conv3_timeline.py)
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].hh, acc[i]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].mm, acc[i]);
+            }
+            // issue order: one load between matrix instructions (a wave blocked on LDS issue cannot issue its matrix
+            // instructions either: tools/conv3_timeline.py)
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
             }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 9; ++r) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
             __builtin_amdgcn_sched_barrier(0);
             a0 = a1;
-            w0 = w1; w1 = w2; w2 = w3;
+            w0 = w1;
         }
         CD_STAMP(1);
         if (cc == NCH - 1) {
-            // D of the 32x32 MFMA: lane (col = t, h) holds rows m = 8 (v >> 2) + (v & 3) + 4 h, v = 0..15; row m of row block
-            // mb is voxel (x = m & 15, y = (m >> 4) + 2 mb, z = wave) -> x = 8 ((v >> 2) & 1) + 4 h + (v & 3), y = (v >> 3) + 2 mb
+            // D of the 32x32 MFMA: lane (col = t, h) holds rows m = 8 (v >> 2) + (v & 3) + 4 h, v = 0..15, of every accumulator;
+            // row m of accumulator i is voxel (x = 4 wave + i, y = m & 7, z = m >> 3).  Each accumulator goes through the wave's
+            // 4 KB of LDS scratch [voxel][channel] and comes back as (voxel, 4 channels) per lane: shift, residual, ReLU,
+            // the fp32 result as float4 (128 B per voxel over 8 lanes) and / or the split operands for the next layer
             int b, ox0, oy0, oz0;
             decode(item, b, ox0, oy0, oz0);
-            const int xl = ox0 + 4 * h, zl = oz0 + wave;
-            const int64_t obase = ((((int64_t)b * X + xl) * Y + oy0) * Z + zl) * O + t;
-            const float sh = shift[t];
-            auto emit = [&](int mb, int v, int64_t idx) {
-                float val = acc[mb][v] + sh;
-                if (MODE == 2) val += res[idx];
-                if (MODE >= 1) val = fmaxf(val, 0.0f);
-                if (MODE == 3) val += res[idx];
+            float *scr = reinterpret_cast<float *>(cd_lds + 2 * CD_BUF) + wave * 1024;
+            const int g = lane & 7;                                          // channel group of this lane on the way out
+            const float4 sh4 = *reinterpret_cast<const float4 *>(shift + 4 * g);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) scr[(8 * (v >> 2) + (v & 3) + 4 * h) * 32 + t] = acc[mb][v];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = (lane >> 3) + 8 * r;
+                    float4 a = *reinterpret_cast<const float4 *>(scr + m * 32 + 4 * g);
+                    const int xo = ox0 + 4 * wave + mb, yo = oy0 + (m & 7), zo = oz0 + (m >> 3);
+                    if (xo < X && yo < Y && zo < Z) {
+                        const int64_t vox = (((int64_t)b * X + xo) * Y + yo) * Z + zo;
+                        a.x += sh4.x; a.y += sh4.y; a.z += sh4.z; a.w += sh4.w;
+                        float4 rr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (MODE >= 2) rr = *reinterpret_cast<const float4 *>(res + vox * O + 4 * g);
+                        if (MODE == 2) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
+                        if (MODE >= 1) { a.x = fmaxf(a.x, 0.0f); a.y = fmaxf(a.y, 0.0f); a.z = fmaxf(a.z, 0.0f); a.w = fmaxf(a.w, 0.0f); }
+                        if (MODE == 3) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
 #if SP3D_W16_ABLATE & 16
-                if (val == 123.456f)
+                        if (a.x == 123.456f)
 #endif
-                y[idx] = val;
-            };
-            if (zl < Z) {
-                if (ox0 + CD_BX <= X && oy0 + CD_BY <= Y) {      // interior block: straight-line stores (64 guarded stores
-#pragma unroll                                                   // became 64 out-of-line branch targets: 13 k cycles)
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v)
-                            emit(mb, v, obase + ((int64_t)(8 * ((v >> 2) & 1) + (v & 3)) * Y + (v >> 3) + 2 * mb) * Z * O);
-                } else {
-#pragma unroll 1
-                    for (int mb = 0; mb < 4; ++mb) {
-#pragma unroll 1
-                        for (int v = 0; v < 16; ++v) {
-                            const int dx = 8 * ((v >> 2) & 1) + (v & 3), dy = (v >> 3) + 2 * mb;
-                            float av = 0.0f;                     // acc[mb][v] with run-time indices: select, no scratch
-#pragma unroll
-                            for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-                                for (int v2 = 0; v2 < 16; ++v2) av = (m2 == mb && v2 == v) ? acc[m2][v2] : av;
-                            if (xl + dx < X && oy0 + dy < Y) {
-                                const int64_t idx = obase + ((int64_t)dx * Y + dy) * Z * O;
-                                float val = av + sh;
-                                if (MODE == 2) val += res[idx];
-                                if (MODE >= 1) val = fmaxf(val, 0.0f);
-                                if (MODE == 3) val += res[idx];
-                                y[idx] = val;
+                        {
+                            if (OUT & 1) *reinterpret_cast<float4 *>(y + vox * O + 4 * g) = a;
+                            if (OUT & 2) {
+                                u32x4 q0, q1;
+                                split3(a, q0, q1);
+                                unsigned *p = ys + (vox * (O / 4) + g) * 8;
+                                *reinterpret_cast<u32x4 *>(p) = q0;
+                                *reinterpret_cast<u32x4 *>(p + 4) = q1;
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
         CD_STAMP(2);
@@ -1206,14 +1251,18 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
-extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,
-                                int B, int X, int Y, int Z, int C, int O, void *stream)
+extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
+                                   const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream)
 {
     using namespace sp3d;
     if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
-    if (!x || !W3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if ((!x && !xs) || !W3 || (!y && !ys) || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
     if (O != 32 || (C != 16 && C != 32) || (reinterpret_cast<uintptr_t>(W3) & 15)) return SP3D_EUNSUPPORTED;
-    if ((int64_t)X * Y * Z * C > 0x7fffffff) return SP3D_ERANGE;
+    if ((reinterpret_cast<uintptr_t>(xs) & 15) || (reinterpret_cast<uintptr_t>(ys) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return SP3D_EUNSUPPORTED;
+    if (ys && mode != 1 && mode != 2) return SP3D_EUNSUPPORTED;                 // split results: the two modes V2V uses
+    if (xs && C != 32) return SP3D_EUNSUPPORTED;
+    if ((int64_t)X * Y * Z * C * 2 > 0x7fffffff) return SP3D_ERANGE;
     const int NBX = (X + CD_BX - 1) / CD_BX, NBY = (Y + CD_BY - 1) / CD_BY, NBZ = (Z + CD_BZ - 1) / CD_BZ;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
@@ -1222,21 +1271,34 @@ extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const 
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    // persistent workgroups, one per CU (142 KB of LDS each), an equal number of blocks each
+    // persistent workgroups, one per CU (158 KB of LDS each), an equal number of blocks each
     const int rounds = (int)((blocks + cus - 1) / cus);
     const int nwg = (int)((blocks + rounds - 1) / rounds);
     const dim3 grid((unsigned)nwg), block(64 * (4 + CD_PROD));
-    const size_t lds = (size_t)2 * CD_BUF * sizeof(unsigned);
+    const size_t lds = (size_t)2 * CD_BUF * sizeof(unsigned) + 4 * 1024 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3);
-#define SP3D_CD(C_, M_) { static bool attr = false; if (!attr) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
-    hipLaunchKernelGGL((conv3_split_kernel<C_, M_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks); }
-#define SP3D_CDM(C_) switch (mode) { case 0: SP3D_CD(C_, 0); break; case 1: SP3D_CD(C_, 1); break; case 2: SP3D_CD(C_, 2); break; default: SP3D_CD(C_, 3); }
-    if (C == 16) { SP3D_CDM(16) } else { SP3D_CDM(32) }
-#undef SP3D_CDM
+    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3), *xs3 = reinterpret_cast<const unsigned *>(xs);
+    unsigned *ys3 = reinterpret_cast<unsigned *>(ys);
+    const int out = (y ? 1 : 0) | (ys ? 2 : 0);
+#define SP3D_CD(C_, M_, I_, O_) { static bool attr = false; if (!attr) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
+    hipLaunchKernelGGL((conv3_split_kernel<C_, M_, I_, O_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks, xs3, ys3); }
+#define SP3D_CDO(C_, M_, I_) { if (out == 1) SP3D_CD(C_, M_, I_, 1) else if (out == 2) SP3D_CD(C_, M_, I_, 2) else SP3D_CD(C_, M_, I_, 3) }
+#define SP3D_CDI(C_, I_) switch (mode) { case 0: SP3D_CD(C_, 0, I_, 1); break; case 1: SP3D_CDO(C_, 1, I_); break; case 2: SP3D_CDO(C_, 2, I_); break; default: SP3D_CD(C_, 3, I_, 1); }
+    if (C == 16) { SP3D_CDI(16, false) }
+    else if (xs) { SP3D_CDI(32, true) }
+    else { SP3D_CDI(32, false) }
+#undef SP3D_CDI
+#undef SP3D_CDO
 #undef SP3D_CD
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,
+                                int B, int X, int Y, int Z, int C, int O, void *stream)
+{
+    if (!x || !y) return SP3D_ENULL;
+    return sp3d_conv3_split_ex(x, nullptr, W3, y, nullptr, shift, residual, mode, B, X, Y, Z, C, O, stream);
 }
 
 extern "C" int sp3d_debug_conv3_timeline(void *dev_buffer)

@@ -1088,3 +1088,34 @@ def test_direct_conv3_split_kernel(shape):
     e, e32 = float((y.double() - ref).abs().max()), float((lib32.double() - ref).abs().max())
     assert e <= 1e-5 * max(1.0, float(ref.abs().max()))
     assert e <= 1.5 * e32 + 1e-6, (e, e32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(2, (16, 12, 8)), (1, (9, 7, 5)), (1, (40, 24, 10))])
+def test_direct_conv3_split_activation_chain(dims):
+    """two layers chained through the split (S3) activation format: conv1 writes ONLY the S3 tensor, conv2 reads it
+    pre-split and adds the residual - bit-identical to the same two layers through fp32 tensors (the split is exact), and
+    the S3 tensor decodes to conv1's fp32 output bit for bit"""
+    from selfpose3d_amd import _lib
+    B, (X, Y, Z) = dims
+    g = torch.Generator(device="cpu").manual_seed(31)
+    x = (torch.randn((B, 32, X, Y, Z), generator=g) * 2.0).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w1 = (torch.randn((32, 32, 3, 3, 3), generator=g) * 0.05).cuda()
+    w2 = (torch.randn((32, 32, 3, 3, 3), generator=g) * 0.05).cuda()
+    s1, s2 = torch.randn(32, generator=g).cuda(), torch.randn(32, generator=g).cuda()
+    W1, W2 = _lib.conv_weights_split(w1), _lib.conv_weights_split(w2)
+    h = _lib.conv3_split_(x, W1, s1, 1)
+    want = _lib.conv3_split_(h, W2, s2, 2, x)
+    none, h3 = _lib.conv3_split_(x, W1, s1, 1, want_f32=False, want_s3=True)
+    assert none is None and h3.shape == (B, X, Y, Z, 8, 8)
+    # decode: dwords [lo01 lo23 hi01 hi23 | hi01 hi23 mid01 mid23], each two bf16 (low half = first channel)
+    d = h3.view(torch.int16).view(B, X, Y, Z, 8, 8, 2).view(torch.bfloat16).float()      # [..., dword, pair]
+    lo = torch.cat([d[..., 0, :], d[..., 1, :]], -1)
+    hi = torch.cat([d[..., 2, :], d[..., 3, :]], -1)
+    mid = torch.cat([d[..., 6, :], d[..., 7, :]], -1)
+    back = ((hi + mid) + lo).reshape(B, X, Y, Z, 32).permute(0, 4, 1, 2, 3)
+    assert torch.equal(back, h)
+    got, got3 = _lib.conv3_split_(None, W2, s2, 2, x, x_s3=h3, want_s3=True)
+    assert torch.equal(got, want)
+    both = _lib.conv3_split_(x, W1, s1, 1, want_s3=True)
+    assert torch.equal(both[0], h) and torch.equal(both[1], h3)

@@ -20,11 +20,13 @@ W3 = _lib.conv_weights_split(w)
 shift = torch.randn(32).cuda()
 y = torch.empty(B, X, Y, Z, 32, device="cuda")
 L = ctypes.CDLL(LIB.replace(".so", "_nostore.so") if "--no-store" in sys.argv else LIB)
-f = L.sp3d_conv3_split
+f = L.sp3d_conv3_split_ex
 f.restype = ctypes.c_int
-f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+x3 = _lib.conv3_split_(x, W3, shift, 1, want_f32=False, want_s3=True)[1] if "--s3" in sys.argv else None
 tl = torch.zeros(8 * 64 * 4, dtype=torch.int64, device="cuda")
-run = lambda: f(x.data_ptr(), W3.data_ptr(), y.data_ptr(), shift.data_ptr(), None, 1, B, X, Y, Z, C, 32, None)
+run = lambda: f(None if x3 is not None else x.data_ptr(), x3.data_ptr() if x3 is not None else None, W3.data_ptr(),
+                y.data_ptr(), None, shift.data_ptr(), None, 1, B, X, Y, Z, C, 32, None)
 for _ in range(3):
     assert run() == 0
 torch.cuda.synchronize()
