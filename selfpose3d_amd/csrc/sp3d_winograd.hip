@@ -1107,6 +1107,27 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
             // the fp32 result as float4 (128 B per voxel over 8 lanes) and / or the split operands for the next layer
             int b, ox0, oy0, oz0;
             decode(item, b, ox0, oy0, oz0);
+            if (OUT == 1 && ox0 + CD_BX <= X && oy0 + CD_BY <= Y && oz0 + CD_BZ <= Z) {
+                // fp32 result only, interior block: straight from the accumulators, lane (t, h) owns channel t of voxels
+                // (x = 4 wave + i, y = 4 h + (v & 3), z = v >> 2); 128-byte rows per store, no LDS round trip (3 k cycles
+                // against 6-9 k for the transposed form below)
+                const float sh = shift[t];
+                const int64_t obase = ((((int64_t)b * X + ox0 + 4 * wave) * Y + oy0 + 4 * h) * Z + oz0) * O + t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int64_t idx = obase + (((int64_t)i * Y + (v & 3)) * Z + (v >> 2)) * O;
+                        float val = acc[i][v] + sh;
+                        if (MODE == 2) val += res[idx];
+                        if (MODE >= 1) val = fmaxf(val, 0.0f);
+                        if (MODE == 3) val += res[idx];
+#if SP3D_W16_ABLATE & 16
+                        if (val == 123.456f)
+#endif
+                        y[idx] = val;
+                    }
+            } else {
             float *scr = reinterpret_cast<float *>(cd_lds + 2 * CD_BUF) + wave * 1024;
             const int g = lane & 7;                                          // channel group of this lane on the way out
             const float4 sh4 = *reinterpret_cast<const float4 *>(shift + 4 * g);
@@ -1146,6 +1167,7 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
             }
         }
         CD_STAMP(2);
