@@ -371,10 +371,16 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
                        "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
                        "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
-                       "step": "heat-maps(HBM, " + handover + "unproject(HIP) -> V2V(fp32: 7^3 opening conv " +
-                               ("rocFFT+HIP contraction" if args.front_conv == "fft" else "MIOpen direct") +
-                               (", 3^3 convs Winograd F(2,3) (fused MFMA kernel / HIP transforms + rocBLAS)" if not args.no_winograd else "") +
+                       "step": "heat-maps(HBM, " + handover + "unproject(HIP) -> V2V(fp32 in/out, fp32 accumulation: 7^3 opening conv " +
+                               ("in the frequency domain (HIP z-DFT + 88x88 plane transforms + contraction)"
+                                if args.front_conv == "fft" else "MIOpen direct") +
+                               (", 3^3 convs as HIP kernels on the bf16 matrix pipe with exact 3-piece operand splits (direct conv at "
+                                "full resolution, fused Winograd F(2,3) at half resolution), Winograd transforms + rocBLAS at quarter "
+                                "resolution" if not args.no_winograd else "") +
                                ", other convs GEMM/MIOpen) -> NMS/top-k(HIP)",
+                       "conv_arithmetic": "fp32 tensors; 3^3 products = 6 exact bf16 x bf16 partial products per fp32 multiply "
+                                          "(hi/mid/lo pieces, dropped terms < 2^-24 relative), fp32 accumulation; error vs float64 "
+                                          "<= that of the fp32 kernels replaced (tests/test_gpu_parity.py)",
                        "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
