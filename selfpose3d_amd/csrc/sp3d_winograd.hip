@@ -1288,10 +1288,14 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
     const int NBX = (X + CD_BX - 1) / CD_BX, NBY = (Y + CD_BY - 1) / CD_BY, NBZ = (Z + CD_BZ - 1) / CD_BZ;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
+    static int cu_count[64] = {0};                     // per device, queried once (hipGetDeviceProperties is slow)
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_count[dev] == 0) {
+            int n = 0;
+            cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        cus = cu_count[dev];
     }
     // persistent workgroups, one per CU (158 KB of LDS each), an equal number of blocks each
     const int rounds = (int)((blocks + cus - 1) / cus);
