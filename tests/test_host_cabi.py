@@ -282,3 +282,28 @@ def test_v2v_inference_plan_key_sees_every_weight_change():
         net._plan = object()
         action()
         assert net._plan is None
+
+
+def test_three_piece_weight_splits_are_exact_and_laid_out_as_documented():
+    """_lib.wino_weights_split / conv_weights_split (host side of the split-product kernels): hi + mid + lo reproduces the
+    fp32 weights bit for bit (8+8+8 mantissa bits), pieces are bf16, records follow the layout include/sp3d.h documents"""
+    import torch
+    from selfpose3d_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.07
+    w[0, 0, 0, 0, 0] = 0.0
+    w[1, 2, 1, 1, 1] = 1e-30          # deep in the subnormal range of the low pieces: must still add up
+    U = _lib.wino_weights(w)
+    for chunk in (8, 16):
+        U3 = _lib.wino_weights_split(U, chunk)
+        assert U3.dtype == torch.bfloat16 and tuple(U3.shape) == (64, 16 // chunk, chunk // 4, 32, 3, 4)
+        mid, hi, lo = U3[..., 0, :].float(), U3[..., 1, :].float(), U3[..., 2, :].float()
+        back = ((hi + mid) + lo).permute(0, 1, 2, 4, 3).reshape(64, 16, 32)     # [p, chunk, group, q, o] -> [p, c, o]
+        assert torch.equal(back, U)
+    W3 = _lib.conv_weights_split(w)
+    assert W3.dtype == torch.bfloat16 and tuple(W3.shape) == (27, 2, 2, 32, 6, 4)
+    hi, lo, hi2, hi3, mid, mid2 = (W3[..., i, :].float() for i in range(6))
+    assert torch.equal(hi, hi2) and torch.equal(hi, hi3) and torch.equal(mid, mid2)
+    back = ((hi + mid) + lo).permute(0, 1, 2, 4, 3).reshape(27, 16, 32)
+    want = w.permute(4, 3, 2, 1, 0).reshape(27, 16, 32)                         # tap = kz*9 + ky*3 + kx
+    assert torch.equal(back, want)
