@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step (configs[1]: 4)")
     ap.add_argument("--roofline-iters", type=int, default=300)
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the extra leg that re-times the step with every 3^3 product on fp32 matrix instructions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-reps", type=int, default=20)
     ap.add_argument("--front-conv", choices=["fft", "direct"], default="fft",
@@ -388,6 +390,32 @@ def main():
         }
         if golden is not None and not args.no_check:
             result["output_check"] = check_output(out, golden)
+        if not args.no_fp32_leg and not args.no_winograd and world == 1:
+            # the same step with the 3^3 products on v_mfma_f32_32x32x2_f32 / rocBLAS fp32 only (no bf16 operand splits):
+            # what the split-product kernels buy, and a number that involves no bf16 instruction at all
+            try:
+                model.v2v_net.wino_split = False
+                model.v2v_net.invalidate_plan()
+                for _ in range(2):
+                    eager_step()
+                torch.cuda.synchronize(dev)
+                alt_step = eager_step
+                if mode == "hipgraph":
+                    from selfpose3d_amd.graphs import GraphedRootNet
+                    g2 = GraphedRootNet(model, hms, meta)
+                    alt_step = (lambda: g2())
+                n2 = max(10, min(50, args.steps))
+                el2, out2 = D.timed_steps(alt_step, n2, 5, dev)
+                result["fp32_matrix_instructions_only"] = {
+                    "value": round(D.job_throughput(B, n2, el2, 1), 3), "unit": "samples/s", "ms_per_step": round(1e3 * el2 / n2, 4),
+                    "steps": n2, "what": "same step, 3^3 convs as fused Winograd on v_mfma_f32_32x32x2_f32 + rocBLAS fp32 GEMMs "
+                                         "(V2VNet.wino_split = False)",
+                    "root_cubes_max_abs_diff_vs_headline": float((out2[0].float() - out[0].float()).abs().max())}
+            except Exception as e:
+                result["fp32_matrix_instructions_only"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                model.v2v_net.wino_split = True
+                model.v2v_net.invalidate_plan()
         result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, args.planar_input,
                                           cold=not args.no_cold)
         if world == 1 and not args.no_cpu_baseline:
