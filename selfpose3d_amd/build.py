@@ -30,19 +30,49 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# per-source extra flags.  sp3d_winograd.hip: no SLP vectorisation - next to matrix instructions the v_pk_add_f32 /
+# v_pk_fma_f32 the vectoriser forms out of the operand transforms cost more than the scalar instructions they replace
+# (half-resolution fused Winograd kernel 83.4 -> 78.5 us); the unprojection kernels, on the other hand, want it.
+PER_SOURCE_FLAGS = {"sp3d_winograd.hip": ["-fno-slp-vectorize"]}
+
+
+def _compile_objects(objdir: str, extra_flags=(), verbose: bool = False):
+    """one hipcc -c per source, in parallel; returns the object paths"""
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + cflags + list(extra_flags) + PER_SOURCE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    return objs
+
+
+def _link(objs, out: str, verbose: bool = False):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + LINK + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def build_variant(out: str, extra_flags=()) -> str:
     """measurement builds (e.g. -DSP3D_TIMELINE for tools/wave_timeline.py); never loaded by the package"""
-    subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", out])
+    objdir = out + ".obj"
+    _link(_compile_objects(objdir, extra_flags), out)
     return out
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objs = _compile_objects(os.path.join(HERE, "build", "obj"), verbose=verbose)
+    _link(objs, LIB + ".tmp", verbose)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
