@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 rm -rf $O/${TAG}_trace
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o bench -- \
-    python $R/bench.py --no-cpu-baseline --no-cold > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace.err   # the bench command minus its CPU leg and its rotating-input leg: the kernel average is then the warm one bench.py reports
+    python $R/bench.py --no-cpu-baseline --no-cold --no-fp32-leg > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace.err   # the bench command minus its CPU leg and its rotating-input leg: the kernel average is then the warm one bench.py reports
 python $R/tools/rocpd_stats.py $O/${TAG}_trace > $O/${TAG}_bench_kernel_stats.md 2>> $O/${TAG}_trace.err
 find $O/${TAG}_trace -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
 rm -rf $O/${TAG}_trace
