@@ -27,7 +27,7 @@ bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64 fine_b10_v5 -1 > /dev/null 2>&1
 bash tools/collect_pmc.sh $O/${TAG}_pmc_fine64_v24 fine_b10_v5 24 > /dev/null 2>&1
 for d in coarse_b4 coarse_b4_cl stress_v10 stress_v10_cl fine64 fine64_v24; do rm -rf $O/${TAG}_pmc_$d/pass*/; done
 # 3. PMC: fused Winograd kernel
-for kind in fp32 split half; do
+for kind in fp32 split half direct; do
   bash tools/pmc_wino_fused.sh $kind > $O/${TAG}_pmc_wino_fused_$kind.txt 2>&1
   cp $O/pmc_wf/summary.json $O/${TAG}_pmc_wino_fused_$kind.json 2>/dev/null
   rm -rf $O/pmc_wf
