@@ -21,6 +21,8 @@
 #include <type_traits>
 
 #include "sp3d_device.h"
+#include "sp3d_proj_pk.h"
+#include "sp3d_unproject_patch.h"
 
 namespace sp3d {
 
@@ -346,7 +348,8 @@ __global__ __launch_bounds__(TILE) void unproject_nhwc_kernel(Views hm, const fl
 //           VALU while they are in flight, then the 64 FMAs of view c.
 // The result tile goes through the wave's LDS slice once and leaves as dwordx4 rows.
 // ------------------------------------------------------------------------------------------
-constexpr int WREC = 2 * 5 * 64;           // floats: [buf][field][voxel]
+constexpr int WREC = 2 * 5 * 64;           // floats: weights [buf][voxel][4] (16-byte records), then offsets [buf][voxel]
+constexpr int WOFF = 2 * 4 * 64;           // first offset word
 constexpr int WOSTR = 68;                  // sOut row stride (floats), rows 16-B aligned
 
 struct Rec {
@@ -354,42 +357,24 @@ struct Rec {
     float w00, w10, w01, w11;
 };
 
+// scalar form of make_record_pk (sp3d_proj_pk.h), used by the backward scatter kernel
 // ESZ: the record's offset is in units of 1/ESZ elements (ESZ = sizeof(element) gives byte offsets)
 template <int JP, int ESZ = 1>
 __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, int h)
 {
+    const RecPk p = make_record_pk(use, v2f{ix, iy}, w, h);
     Rec r;
-    const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const float wx = ix - fx0, ex = 1.0f - wx, ny = iy - fy0, sy = 1.0f - ny;
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    // does any used voxel of the wave have a tap in the zero padding (x0 == -1 | w-1, y0 == -1 | h-1)?
-    const bool edge = use && (((unsigned)x0 > (unsigned)(w - 2)) || ((unsigned)y0 > (unsigned)(h - 2)));
-    if (!__any(edge)) {
-        // common case: all four taps in range; voxels not seen by this camera get zero x-weights at offset 0
-        const float fxl = use ? ex : 0.0f, fxr = use ? wx : 0.0f;
-        r.w00 = sy * fxl; r.w10 = sy * fxr; r.w01 = ny * fxl; r.w11 = ny * fxr;
-        r.off = use ? (y0 * w + x0) * (JP * ESZ) : 0;
-        return r;
-    }
-    // clamp the 2x2 block inside the image; d = shift of the block relative to the true taps:
-    //   0: both taps in range; +1: only the right/bottom tap (x0 == -1), it now sits in the
-    //   left/top slot; -1: only the left/top tap (x0 == w-1), now in the right/bottom slot;
-    //   anything else: both taps fall in the zero padding.
-    const int x0c = min(max(x0, 0), w - 2), y0c = min(max(y0, 0), h - 2);
-    const int dxs = use ? x0c - x0 : 99, dys = y0c - y0;
-    const float fxl = dxs == 0 ? ex : (dxs == 1 ? wx : 0.0f);
-    const float fxr = dxs == 0 ? wx : (dxs == -1 ? ex : 0.0f);
-    const float fyt = dys == 0 ? sy : (dys == 1 ? ny : 0.0f);
-    const float fyb = dys == 0 ? ny : (dys == -1 ? sy : 0.0f);
-    r.w00 = fyt * fxl; r.w10 = fyt * fxr; r.w01 = fyb * fxl; r.w11 = fyb * fxr;
-    r.off = (y0c * w + x0c) * (JP * ESZ);
+    r.off = (p.y0 * w + p.x0) * (JP * ESZ);
+    r.w00 = p.wt.x; r.w10 = p.wt.y; r.w01 = p.wb.x; r.w11 = p.wb.y;
     return r;
 }
 
 // The view loop shared by the pipelined kernels: P1 (lane = voxel) and G (lane = (voxel-of-4, channel quad)) for the 64
 // voxels of this wave; `x,y,z` is this lane's voxel centre, `inb` whether the lane has a voxel at all.  On return
 // acc[i][k] holds sum over views of the bilinear samples of voxel slot 16*i + lane/4, channel 4*(lane%4) + k, and
-// mymask the bound bits of the lane's own voxel (+ bit 31: NaN sample position).
+// mymask = number of views that see the lane's own voxel (+ bit 31: NaN sample position).
+// Round 3: the projection runs on packed fp32 pairs (sp3d_proj_pk.h), a tap record is one 16-byte weight quad + one
+// offset word (2 LDS instructions per slot instead of 5), the interpolation is written on channel pairs.
 template <int JP, typename TI, int U = 4>
 __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restrict__ cam, const Geom &g, int bs, float x,
                                            float y, float z, bool inb, float *ws, int lane, float (&acc)[4][4],
@@ -397,6 +382,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
 {
     constexpr int NQ = JP / 4;
     int *wsi = reinterpret_cast<int *>(ws);
+    float4 *ws4 = reinterpret_cast<float4 *>(ws);
     (void)tl;
     SP3D_DIAG_FLAGS();
 #ifdef SP3D_DIAG
@@ -409,32 +395,24 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
         const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
 #ifdef SP3D_DIAG
         if (SP3D_DIAG_ON(4)) {      // no projection: a fixed record per lane (distinct pixels, in range)
-            if (inb) mymask |= (1u << c);
-            const int base = (c & 1) * 320 + lane;
-            wsi[base] = (int)((unsigned)(lane * 37 + c * 4001 + 1000 + (int)(x * 0.01f)) % (unsigned)(g.w * (g.h - 2))) * (JP * (int)sizeof(TI));
-            ws[base + 64] = 0.25f; ws[base + 128] = 0.25f; ws[base + 192] = 0.25f; ws[base + 256] = 0.25f;
+            if (inb) mymask += 1u;
+            const int v = (c & 1) * 64 + lane;
+            wsi[WOFF + v] = (int)((unsigned)(lane * 37 + c * 4001 + 1000 + (int)(x * 0.01f)) % (unsigned)(g.w * (g.h - 2))) * (JP * (int)sizeof(TI));
+            ws4[v] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
             return true;
         }
 #endif
-        float y0, y1, px, py, ix, iy;
-        bool isnan;
-        proj_a(cm, x, y, z, y0, y1);
-        const bool bound = proj_b(cm, y0, y1, px, py, isnan) && inb;
-        if (bound) mymask |= (1u << c);
-        if (isnan && inb) mymask |= 0x80000000u;
-        // nobody in this wave is inside image c: skip the crop affine .. record.  The only thing the rest could
-        // still add is a NaN born in the affine stage, which needs a non-finite affine row (checked on the scalar unit)
-        if (!__any(bound && !isnan) && affine_finite(cm)) return false;
-        bool isnan_c = false;
-        proj_c(cm, g, px, py, ix, iy, isnan_c);
-        if (isnan_c && inb) mymask |= 0x80000000u;
-        isnan = isnan || isnan_c;
-        const bool use = bound && !isnan;
-        if (!__any(use)) return false;          // no voxel of this wave sees camera c
-        const Rec r = make_record<JP, (int)sizeof(TI)>(use, isnan ? 0.0f : ix, isnan ? 0.0f : iy, g.w, g.h);
-        const int base = (c & 1) * 320 + lane;
-        wsi[base] = r.off;
-        ws[base + 64] = r.w00; ws[base + 128] = r.w10; ws[base + 192] = r.w01; ws[base + 256] = r.w11;
+        P1State st;
+        const bool go = project_pk(cm, g, x, y, z, inb, st);
+        add_mask(mymask, st.bm);
+        if (st.nm != 0ull && lane_of(st.nm)) mymask |= 0x80000000u;
+        if (!go) return false;
+        const unsigned long long um = st.bm & ~st.nm;
+        if (um == 0ull) return false;           // no voxel of this wave sees camera c
+        const RecPk r = make_record_pk(lane_of(um), st.i, g.w, g.h);
+        const int v = (c & 1) * 64 + lane;
+        wsi[WOFF + v] = (int)__umul24((unsigned)(JP * (int)sizeof(TI)), __umul24((unsigned)r.y0, (unsigned)g.w) + (unsigned)r.x0);
+        ws4[v] = make_float4(r.wt.x, r.wt.y, r.wb.x, r.wb.y);
         return true;
     };
 
@@ -453,7 +431,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
         // {vb, vb2} + off (+ JP as an immediate), no 64-bit VALU address arithmetic
         const char *vb = reinterpret_cast<const char *>(reinterpret_cast<const TI *>(hm.p[c]) + (size_t)bs * g.h * rowf);
         const char *vb2 = vb + rowf * sizeof(TI);
-        const int rb = (c & 1) * 320 + g16;
+        const int rb = (c & 1) * 64 + g16;
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -472,7 +450,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
             if (cur) {
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    const uint32_t off = (uint32_t)wsi[rb + 16 * (gi * U + k)] + qoff;      // bytes
+                    const uint32_t off = (uint32_t)wsi[WOFF + rb + 16 * (gi * U + k)] + qoff;      // bytes
                     t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
                     t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
                     t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
@@ -490,13 +468,14 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     const int i = gi * U + k;
-                    const float w00 = ws[rb + 16 * i + 64], w10 = ws[rb + 16 * i + 128];
-                    const float w01 = ws[rb + 16 * i + 192], w11 = ws[rb + 16 * i + 256];
-                    float v;
-                    v = t00[k].x * w00; v = fmaf(t10[k].x, w10, v); v = fmaf(t01[k].x, w01, v); v = fmaf(t11[k].x, w11, v); acc[i][0] = acc[i][0] + v;
-                    v = t00[k].y * w00; v = fmaf(t10[k].y, w10, v); v = fmaf(t01[k].y, w01, v); v = fmaf(t11[k].y, w11, v); acc[i][1] = acc[i][1] + v;
-                    v = t00[k].z * w00; v = fmaf(t10[k].z, w10, v); v = fmaf(t01[k].z, w01, v); v = fmaf(t11[k].z, w11, v); acc[i][2] = acc[i][2] + v;
-                    v = t00[k].w * w00; v = fmaf(t10[k].w, w10, v); v = fmaf(t01[k].w, w01, v); v = fmaf(t11[k].w, w11, v); acc[i][3] = acc[i][3] + v;
+                    const float4 wq = ws4[rb + 16 * i];                 // (w00, w10, w01, w11)
+                    // ATen's bilinear chain per channel: fma(se, wse, fma(sw, wsw, fma(ne, wne, nw * wnw)))
+                    v2f lo = v2f{t00[k].x, t00[k].y} * pk2(wq.x), hi = v2f{t00[k].z, t00[k].w} * pk2(wq.x);
+                    lo = pk_fma(v2f{t10[k].x, t10[k].y}, pk2(wq.y), lo); hi = pk_fma(v2f{t10[k].z, t10[k].w}, pk2(wq.y), hi);
+                    lo = pk_fma(v2f{t01[k].x, t01[k].y}, pk2(wq.z), lo); hi = pk_fma(v2f{t01[k].z, t01[k].w}, pk2(wq.z), hi);
+                    lo = pk_fma(v2f{t11[k].x, t11[k].y}, pk2(wq.w), lo); hi = pk_fma(v2f{t11[k].z, t11[k].w}, pk2(wq.w), hi);
+                    const v2f a0 = v2f{acc[i][0], acc[i][1]} + lo, a1 = v2f{acc[i][2], acc[i][3]} + hi;
+                    acc[i][0] = a0.x; acc[i][1] = a0.y; acc[i][2] = a1.x; acc[i][3] = a1.y;
                 }
             }
         }
@@ -582,10 +561,10 @@ __device__ __forceinline__ void pipe_tile(const Views &hm, const float *__restri
         tl[28] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
         tl[29] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
     }
-    if (tl && lane == 0) tl[31] = (unsigned long long)__popc(mymask);
+    if (tl && lane == 0) tl[31] = (unsigned long long)(mymask & 0x7fffffffu);
 #endif
     // per voxel (P1 mapping, once): den = #views seeing it + 1e-6, rden = RN(1/den), 0 for a NaN sample position
-    const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+    const float den_l = (float)(mymask & 0x7fffffffu) + 1e-6f;
     const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -751,7 +730,7 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
 
         // view fusion (project_layer.py:96-99) on the gather mapping
         __builtin_amdgcn_wave_barrier();
-        const float den_l = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+        const float den_l = (float)(mymask & 0x7fffffffu) + 1e-6f;
         const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1215,6 +1194,13 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     if (Jp < g.J || (Jp & 3) || Jp > 16) return SP3D_EUNSUPPORTED;
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
     if (g.w < 2 || g.h < 2) variant &= ~(8 | 32);                // the clamped 2x2 block needs a 2x2 image
+    if ((int64_t)g.h * g.w > (1 << 24)) variant &= ~(8 | 32);    // the pipelined kernels form pixel indices with 24-bit multiplies
+    if ((variant & 128) && Jp == 16 && g.w >= 2 && g.h >= 2 && (int64_t)g.h * g.w <= (1 << 24) && g.w < 65536 && g.h < 65536) {
+        // LDS-staged patches (dense grids): sp3d_unproject_patch.hip
+        const int rc = launch_patch(v, Jp, cam, centers, valid, cubes, grids, g, out_cl, io, s);
+        return rc ? rc : launch_status();
+    }
+    variant &= ~128;
     if (variant & 32) variant |= 8;
     if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
     if (io) variant |= 16;

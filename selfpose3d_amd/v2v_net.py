@@ -290,20 +290,28 @@ class _FoldedV2V:
         r = x if ws is None else self._conv1(x, ws)
         return self._conv3(h, w2, u2, s2, 2, r)
 
-    # -- library GEMM selection ---------------------------------------------------------------------------------
+    # -- library GEMM selection (OPT-IN) ---------------------------------------------------------------------------
     # The plan's GEMMs (batched Winograd products, transposed-conv and 1x1x1 GEMMs) are plain library calls; which
     # rocBLAS / hipBLASLt solution the library's heuristic picks matters: the 64 x (8000 x 64 x 64) batched product of a
     # half-resolution layer runs 85 us with the default solution and 47 us with the best one (tools/exp_blas.sh).
-    # PyTorch's TunableOp does that selection: the FIRST eager forward of each input shape runs with tuning on (a few
-    # ms per GEMM shape, never during graph capture), later forwards only look the choice up.  SP3D_TUNE_GEMM=0: off.
+    # PyTorch's TunableOp can do that selection, but it is PROCESS-WIDE state and its choice comes from timing, so a
+    # library forward must not switch it on behind the caller's back (round-2 advisor finding).  It is therefore off
+    # unless the caller asks: ``V2VNet.tune_gemms(True)`` (what bench.py does, and says so in its JSON line) or
+    # SP3D_TUNE_GEMM=1.  When on: the FIRST eager forward of each input shape runs with tuning enabled (a few ms per
+    # GEMM shape, never during graph capture); later forwards only look the selection up.  TunableOp's enabled /
+    # tuning flags are restored to the caller's values when the forward returns, its results file is neither renamed
+    # nor written by this code: set PYTORCH_TUNABLEOP_FILENAME yourself to persist selections, and load the same
+    # file on every rank (PYTORCH_TUNABLEOP_TUNING=0) for run-to-run / rank-to-rank identical kernels.
     _tuned_shapes: "set[tuple]" = set()
+    _tune_gemms = None                 # None: follow SP3D_TUNE_GEMM (default off); True / False: explicit
 
     @staticmethod
     def _tunable():
         import os
-        if os.environ.get("SP3D_TUNE_GEMM", "1") in ("0", ""):
-            return None
-        return getattr(torch.cuda, "tunable", None)
+        on = _FoldedV2V._tune_gemms
+        if on is None:
+            on = os.environ.get("SP3D_TUNE_GEMM", "0") not in ("0", "")
+        return getattr(torch.cuda, "tunable", None) if on else None
 
     def _run_tuned(self, x):
         tun = self._tunable()
@@ -313,14 +321,7 @@ class _FoldedV2V:
         shape_key = (tuple(x.shape), str(x.device), bool(self.net.winograd), bool(self.net.fft_front))
         was_on, was_tuning = tun.is_enabled(), tun.tuning_is_enabled()
         try:
-            if not was_on:
-                tun.enable(True)
-                if hasattr(tun, "write_file_on_exit"):
-                    tun.write_file_on_exit(False)          # selections live in this process only
-                else:                                      # (this torch writes them at exit: keep the cwd clean)
-                    import os
-                    import tempfile
-                    tun.set_filename(os.path.join(tempfile.gettempdir(), f"sp3d_tunableop_{os.getpid()}.csv"))
+            tun.enable(True)
             first = shape_key not in _FoldedV2V._tuned_shapes and not capturing
             tun.tuning_enable(bool(first))
             if first:
@@ -329,9 +330,9 @@ class _FoldedV2V:
             if first:
                 _FoldedV2V._tuned_shapes.add(shape_key)
             return out
-        finally:
-            tun.tuning_enable(was_tuning)
-            # lookups stay enabled: a later forward (or graph replay capture) must find the selections
+        finally:                       # the caller's process-wide settings come back; the selections stay in TunableOp's
+            tun.tuning_enable(was_tuning)      # in-memory table and are found again by the next forward of this plan
+            tun.enable(was_on)
 
     @torch.no_grad()
     def run(self, x):
@@ -535,8 +536,19 @@ class V2VNet(nn.Module):
         return self
 
     def train(self, mode: bool = True):
-        self._plan = None                      # weights are about to change (or just did)
+        # the folded plan is dropped when the module ENTERS training (weights are about to change); model.eval() on a
+        # module that already is in eval mode - every validation pass calls it - keeps the plan (and its padded
+        # buffers).  Weight edits while in eval mode are still caught by the plan's (data_ptr, version) key.
+        if mode and not self.training:
+            self._plan = None
         return super().train(mode)
+
+    @staticmethod
+    def tune_gemms(on: bool = True):
+        """opt in (or out) of library-GEMM selection through PyTorch's TunableOp for the inference plan's GEMMs
+        (process-wide TunableOp state is touched only inside the plan's forward and restored afterwards; see
+        _FoldedV2V._run_tuned).  Default: off, or SP3D_TUNE_GEMM=1."""
+        _FoldedV2V._tune_gemms = None if on is None else bool(on)
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._plan = None

@@ -90,6 +90,34 @@ def test_nhwc_variants_bit_identical(dev, variant):
     assert torch.equal(base, got)
 
 
+@pytest.mark.parametrize("name", gio.SMALL_CASES + gio.FULL_CASES)
+def test_patch_kernel_bit_identical(dev, name):
+    """LDS-staged patch kernel (variant 128, sp3d_unproject_patch.hip) == the planar kernel, bit for bit, in both result
+    layouts, on every golden case with 13-16 channels (coarse, fine, augmented, invalid rows, V=10 stress grid): whatever
+    mix of staged patches / direct-gather fall-backs the workgroups take, the values are the same."""
+    from selfpose3d_amd import _lib
+    case = gio.Case(name)
+    if case.J <= 12 or min(case.hm) < 2:
+        pytest.skip("the patch kernel takes 16-float pixels")
+    base, _ = _hip_fwd(case, dev, "planar")
+    got, grids = _hip_fwd(case, dev, "nhwc", variant=128, want_grids=True)
+    assert torch.equal(base, got)
+    _, ref_g = _oracle_fwd(case)
+    assert np.array_equal(grids.cpu().numpy(), ref_g)
+    # channels-last result (B, X, Y, Z, 16): the 16 packed channels, pad channel = 0
+    w, h = case.hm
+    hms = [x.to(dev) for x in case.hms]
+    packed = _lib.pack_heatmaps(hms, jp=16)
+    cam = torch.from_numpy(case.cam).to(dev)
+    centers = torch.from_numpy(case.centers).to(dev)
+    valid = torch.from_numpy(case.valid).to(dev)
+    cl, _ = _lib.unproject_fwd([packed[c] for c in range(case.V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, case.B, 16,
+                               h, w, case.cube, case.grid_size, case.img, False, variant=128, channels_last=True)
+    assert tuple(cl.shape) == (case.B, 16, *case.cube)          # a (B,16,X,Y,Z) view of (B,X,Y,Z,16) memory
+    assert torch.equal(cl[:, :case.J], base)
+    assert torch.count_nonzero(cl[:, case.J:]) == 0
+
+
 def test_no_grids_and_invalid_rows(dev):
     case = gio.Case("unproj_fine_small")          # row 1 is invalid (flag < 0)
     for layout in ("planar", "nhwc"):
