@@ -266,7 +266,7 @@ def test_project_joints_matches_reference_project_pose_batch():
 
 
 def test_v2v_inference_plan_key_sees_every_weight_change():
-    """the folded plan must not survive memory-format changes, in-place writes, train() or load_state_dict"""
+    """the folded plan must not survive memory-format changes, in-place writes, entering train() or load_state_dict"""
     from selfpose3d_amd.v2v_net import V2VNet, _FoldedV2V
     net = V2VNet(2, 1).eval()
     k0 = _FoldedV2V._key(net)
@@ -277,11 +277,18 @@ def test_v2v_inference_plan_key_sees_every_weight_change():
     with torch.no_grad():
         net.encoder_decoder.mid_res.res_branch[0].weight.mul_(2.0)
     assert _FoldedV2V._key(net) != k1
-    for action in (lambda: net.train(), lambda: net.eval(), lambda: net.load_state_dict(net.state_dict()),
-                   lambda: net.invalidate_plan()):
+    for action in (lambda: net.train(), lambda: net.load_state_dict(net.state_dict()), lambda: net.invalidate_plan()):
+        net.eval()
         net._plan = object()
         action()
         assert net._plan is None
+    # eval() on a module that already is in eval mode (every validation pass calls it) keeps the plan and its
+    # padded buffers; weight edits made in eval mode are caught by the (data_ptr, version) key checked above
+    net.eval()
+    marker = net._plan = object()
+    net.eval()
+    assert net._plan is marker
+    net._plan = None
 
 
 def test_three_piece_weight_splits_are_exact_and_laid_out_as_documented():

@@ -40,7 +40,7 @@ run = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, vali
                                  variant=128, channels_last=True)
 for _ in range(5): run()
 S = 32
-nwave = 4 * 8 * 40000
+nwave = 8 * 60000
 buf = torch.zeros(nwave * S, dtype=torch.int64, device=dev)
 lib.sp3d_debug_set_patch_timeline.argtypes = [ctypes.c_void_p]
 assert lib.sp3d_debug_set_patch_timeline(buf.data_ptr()) == 0
@@ -51,13 +51,12 @@ t = buf.cpu().numpy().reshape(-1, S).astype(np.float64)
 t = t[t[:, 0] != 0]
 d = lambda a, b: float(np.mean(t[:, b] - t[:, a]))
 out = {"workload": which, "waves": int(len(t)), "kernel_us_event": round(e0.elapsed_time(e1) * 1e3, 1),
-       "cycles": {"life": d(0, 29), "corner_pass+barrier": d(0, 1), "issue(0)+P1(0)": d(1, 2)},
-       "last_view_mode_hist": {int(k): int((t[:, 31] == k).sum()) for k in (0, 1, 2)}}
-nv = min(V, 5)
+       "cycles": {"life": d(0, 29), "setup+P1(0)+issue(0)": d(0, 1)}}
+nv = min(V, 6)
 for c in range(nv):
-    b0 = 3 + 5 * c
-    prev = 2 if c == 0 else 7 + 5 * (c - 1)
-    out["cycles"][f"view{c}"] = {"wait+barrier": d(prev, b0), "issue_next": d(b0, b0 + 1), "tap_reads_issue": d(b0 + 1, b0 + 2),
-                                 "P1_next": d(b0 + 2, b0 + 3), "interp": d(b0 + 3, b0 + 4)}
+    b0 = 2 + 4 * c
+    prev = 1 if c == 0 else 5 + 4 * (c - 1)
+    out["cycles"][f"view{c}"] = {"P1_next": d(prev, b0), "wait_patch+tap_reads_issue": d(b0, b0 + 1),
+                                 "wait_taps+issue_next_patch": d(b0 + 1, b0 + 2), "interp": d(b0 + 2, b0 + 3)}
 out["cycles"]["fusion+stores"] = d(28, 29)
 print(json.dumps(out, indent=1))
