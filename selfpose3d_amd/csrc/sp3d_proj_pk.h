@@ -52,15 +52,21 @@ __device__ __forceinline__ float umax_f32(float a, float b)
 // and div_const's reciprocal form equals the IEEE division; larger or non-finite rows take the IEEE form.
 __device__ __forceinline__ bool affine_tame(const float *__restrict__ cm)
 {
-    bool ok = true;
+    // branch-free on purpose: max of the six magnitudes (as integers) on the scalar unit; the && chain this replaces
+    // compiled to five load + wait + test + branch groups per view
+    uint32_t m = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ok = ok && ((__float_as_uint(cm[SP3D_CAM_A + i]) & 0x7fffffffu) <= 0x7149f2cau);   // 1e30f
-    return ok;
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t a = __float_as_uint(cm[SP3D_CAM_A + i]) & 0x7fffffffu;
+        m = a > m ? a : m;
+    }
+    return m <= 0x7149f2cau;                       // 1e30f
 }
 
+// inbm: lanes that own a voxel (ballot of `inb`, computed once per wave by the caller)
 template <bool EARLY_OUT = true>
-__device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const Geom &g, float x, float y, float z, bool inb,
-                                           P1State &o)
+__device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const Geom &g, float x, float y, float z,
+                                           unsigned long long inbm, P1State &o)
 {
     // --- camera transform + perspective division (cameras.py:40-42); torch's K=3 mm is an fma chain
     const v2f dxy = v2f{x, y} - v2f{cm[SP3D_CAM_T + 0], cm[SP3D_CAM_T + 1]};
@@ -71,9 +77,11 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
     const float zc = fmaf(cm[8], dz, fmaf(cm[7], dxy.y, cm[6] * dxy.x));
     const float den = zc + 1e-5f;
     v2f yn;
-    {   // div_pair (sp3d_device.h) on the pair
+    {   // div_pair (sp3d_device.h) on the pair; one lane out of the reciprocal form's range sends the whole wave through
+        // the IEEE division (same results, no exec-mask juggling on the common path)
         const float ad = __builtin_fabsf(den);
-        if (__builtin_expect(!(ad >= 1e-20f && ad <= 1e20f), 0)) {
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ad >= 1e-20f) & __builtin_amdgcn_ballot_w64(ad <= 1e20f);
+        if (__builtin_expect(okm != __builtin_amdgcn_ballot_w64(true), 0)) {
             yn = v2f{c2.x / den, c2.y / den};
         } else {
             float r = __builtin_amdgcn_rcpf(den);
@@ -100,10 +108,8 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
     const float W0 = cm[SP3D_CAM_W0], H0 = cm[SP3D_CAM_H0];
     // in-image test on the unclamped pixel (project_layer.py:78-79): four compares combined on the scalar unit
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(p.x >= 0.0f) & __builtin_amdgcn_ballot_w64(p.y >= 0.0f) &
-                                  __builtin_amdgcn_ballot_w64(p.x < W0) & __builtin_amdgcn_ballot_w64(p.y < H0) &
-                                  __builtin_amdgcn_ballot_w64(inb);
-    const unsigned long long nm = (__builtin_amdgcn_ballot_w64(p.x != p.x) | __builtin_amdgcn_ballot_w64(p.y != p.y)) &
-                                  __builtin_amdgcn_ballot_w64(inb);
+                                  __builtin_amdgcn_ballot_w64(p.x < W0) & __builtin_amdgcn_ballot_w64(p.y < H0) & inbm;
+    const unsigned long long nm = (__builtin_amdgcn_ballot_w64(p.x != p.x) | __builtin_amdgcn_ballot_w64(p.y != p.y)) & inbm;
     o.bm = bm; o.nm = nm;
     const bool aff_ok = affine_tame(cm);
     // nobody in this wave is inside image c: the only thing the rest could still add is a NaN born in the affine stage,
@@ -132,8 +138,7 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
     } else {                                                          // infinite q: div_const would turn it into NaN, IEEE keeps it
         gn.x = q.x * (float)g.w / W_in / (float)(g.w - 1) * 2.0f - 1.0f;
         gn.y = q.y * (float)g.h / H_in / (float)(g.h - 1) * 2.0f - 1.0f;
-        o.nm |= (__builtin_amdgcn_ballot_w64(gn.x != gn.x) | __builtin_amdgcn_ballot_w64(gn.y != gn.y)) &
-                __builtin_amdgcn_ballot_w64(inb);                    // non-finite camera tables only
+        o.nm |= (__builtin_amdgcn_ballot_w64(gn.x != gn.x) | __builtin_amdgcn_ballot_w64(gn.y != gn.y)) & inbm;   // non-finite camera tables only
     }
     gn.x = clamp_fast(gn.x, -1.1f, 1.1f);
     gn.y = clamp_fast(gn.y, -1.1f, 1.1f);

@@ -391,6 +391,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
         for (unsigned k = 0; k < (hw & 3u); ++k) __builtin_amdgcn_s_sleep(8);
     }
 #endif
+    const unsigned long long inbm = __builtin_amdgcn_ballot_w64(inb);
     auto P1 = [&](int c) -> bool {
         const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
 #ifdef SP3D_DIAG
@@ -403,7 +404,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
         }
 #endif
         P1State st;
-        const bool go = project_pk(cm, g, x, y, z, inb, st);
+        const bool go = project_pk(cm, g, x, y, z, inbm, st);
         add_mask(mymask, st.bm);
         if (st.nm != 0ull && lane_of(st.nm)) mymask |= 0x80000000u;
         if (!go) return false;
@@ -451,10 +452,12 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     const uint32_t off = (uint32_t)wsi[WOFF + rb + 16 * (gi * U + k)] + qoff;      // bytes
-                    t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
-                    t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
-                    t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
+                    // (issued in the reverse of the order the interpolation consumes them: loads return in order, so
+                    // the wait for t00 covers the slot's other three and the chain needs one s_waitcnt per slot, not four)
                     t11[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off) + JP);
+                    t01[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb2 + off));
+                    t10[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off) + JP);
+                    t00[k] = Store4<TI>::load(reinterpret_cast<const TI *>(vb + off));
                 }
             }
             if (gi == 0) {

@@ -144,12 +144,13 @@ __global__ __launch_bounds__(64, 4) void unproject_wpatch_kernel(Views hm, const
     for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
     const uint32_t lane16 = (uint32_t)lane * 16u;
 
+    const unsigned long long inbm = __builtin_amdgcn_ballot_w64(inb);
     // P1(c): tap records of the brick in view c.  Returns 0: no voxel sees the view, 1: the records hold global byte
     // offsets (direct gather), 2: they hold byte offsets inside the LDS patch described by `box`.
     auto P1 = [&](int c, PatchBox &box) -> int {
         const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
         P1State st;
-        const bool go = project_pk(cm, g, x, y, z, inb, st);
+        const bool go = project_pk(cm, g, x, y, z, inbm, st);
         add_mask(mymask, st.bm);
         if (st.nm != 0ull && lane_of(st.nm)) mymask |= 0x80000000u;
         if (!go) return 0;
