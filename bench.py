@@ -107,7 +107,7 @@ def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winogr
     return cfg, meta, hms, model, golden
 
 
-def check_output(out, golden, tol=2e-4):
+def check_output(out, golden, tol=5e-5):
     """the step's own output (rank 0, samples 0,1) against the reference CuboidProposalNet -> V2VNet -> nms golden"""
     from selfpose3d_amd import synthetic as syn
     root_cubes, grid_centers = out
@@ -381,8 +381,10 @@ def main():
                                 "resolution" if not args.no_winograd else "") +
                                ", other convs GEMM/MIOpen) -> NMS/top-k(HIP)",
                        "conv_arithmetic": "fp32 tensors; 3^3 products = 6 exact bf16 x bf16 partial products per fp32 multiply "
-                                          "(hi/mid/lo pieces, dropped terms < 2^-24 relative), fp32 accumulation; error vs float64 "
-                                          "<= that of the fp32 kernels replaced (tests/test_gpu_parity.py)",
+                                          "(hi/mid/lo pieces, dropped terms < 2^-24 relative), fp32 accumulation; tested bound: "
+                                          "max error vs a float64 convolution <= 1.5x that of the fp32-MFMA kernel on the same "
+                                          "inputs (tests/test_gpu_parity.py); measured 2.3e-6 (split Winograd) / 9.1e-6 (direct split) "
+                                          "vs 2.4e-6 (fp32 MFMA) / 9.3e-6 (MIOpen direct fp32) on outputs of magnitude 8",
                        "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},

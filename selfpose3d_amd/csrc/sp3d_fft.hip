@@ -4,8 +4,12 @@
 // C2R inputs) - three ~55 MB copies per root-net step that the plan here does not need, because the padded input
 // buffer is only read by the R2C plan and the spectrum is scratch that the C2R plan is allowed to destroy.
 //
-// Plans are cached per (device, direction, batch, SX, SY, SZ); the first call of a shape builds the plan (and its work
-// buffer), so it must not happen inside a stream capture - later calls only enqueue kernels on `stream`.
+// Plans are cached per (device, STREAM, direction, batch, SX, SY, SZ); the first call of a shape on a stream builds the
+// plan (and its work buffer), so it must not happen inside a stream capture - later calls only enqueue kernels on
+// `stream`.  A plan's work buffer belongs to one stream: transforms of the same shape enqueued on two streams (an eager
+// call next to a graph captured elsewhere) use different plans and cannot race on scratch memory (advisor, round 2).
+// A captured forward borrows the plan its eager warm-up built (a capturing stream cannot allocate): do not run eager
+// transforms of that shape on the warm-up stream while a replay of such a graph is in flight on another stream.
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
 #include <stdint.h>
@@ -17,21 +21,37 @@
 #include "../../include/sp3d.h"
 
 namespace {
-using Key = std::tuple<int, int, int, int, int, int>;       // device, kind (0 R2C 3-D, 1 C2R 3-D, 2 C2C 2-D), batch, SX, SY, SZ
+// device, stream, kind (0 R2C 3-D, 1 C2R 3-D, 2 C2C 2-D), batch, SX, SY, SZ
+using Key = std::tuple<int, uintptr_t, int, int, int, int, int>;
 std::mutex g_mu;
 std::map<Key, hipfftHandle> g_plans;
 
-int get_plan(int inverse, int batch, int SX, int SY, int SZ, hipfftHandle *out)
+int get_plan(int inverse, int batch, int SX, int SY, int SZ, void *stream, hipfftHandle *out)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    const Key k{dev, inverse, batch, SX, SY, SZ};
+    const Key k{dev, (uintptr_t)stream, inverse, batch, SX, SY, SZ};
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_plans.find(k);
     if (it != g_plans.end()) {
         *out = it->second;
         return SP3D_OK;
+    }
+    // a stream that is being captured cannot build a plan (work-buffer allocation): it borrows the plan an eager
+    // (warm-up) call of the same shape built on this device.  PyTorch captures on a private side stream, so this is the
+    // normal path of a captured forward.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+        for (auto &kv : g_plans) {
+            const Key &o = kv.first;
+            if (std::get<0>(o) == dev && std::get<2>(o) == inverse && std::get<3>(o) == batch && std::get<4>(o) == SX &&
+                std::get<5>(o) == SY && std::get<6>(o) == SZ) {
+                *out = kv.second;
+                return SP3D_OK;
+            }
+        }
+        return SP3D_EFFT;       // no plan of this shape yet: run the forward once eagerly before capturing it
     }
     hipfftHandle p;
     int n[3] = {SX, SY, SZ};
@@ -58,7 +78,7 @@ extern "C" int sp3d_rfft3d(const float *in, float *out, int batch, int SX, int S
     int rc = check_args(in, out, batch, SX, SY, SZ);
     if (rc) return rc;
     hipfftHandle p;
-    if ((rc = get_plan(0, batch, SX, SY, SZ, &p))) return rc;
+    if ((rc = get_plan(0, batch, SX, SY, SZ, stream, &p))) return rc;
     std::lock_guard<std::mutex> lock(g_mu);              // SetStream + Exec of one plan must not interleave
     if (hipfftSetStream(p, (hipStream_t)stream) != HIPFFT_SUCCESS) return SP3D_EFFT;
     if (hipfftExecR2C(p, const_cast<float *>(in), reinterpret_cast<hipfftComplex *>(out)) != HIPFFT_SUCCESS) return SP3D_EFFT;
@@ -70,7 +90,7 @@ extern "C" int sp3d_irfft3d(float *in, float *out, int batch, int SX, int SY, in
     int rc = check_args(in, out, batch, SX, SY, SZ);
     if (rc) return rc;
     hipfftHandle p;
-    if ((rc = get_plan(1, batch, SX, SY, SZ, &p))) return rc;
+    if ((rc = get_plan(1, batch, SX, SY, SZ, stream, &p))) return rc;
     std::lock_guard<std::mutex> lock(g_mu);
     if (hipfftSetStream(p, (hipStream_t)stream) != HIPFFT_SUCCESS) return SP3D_EFFT;
     if (hipfftExecC2R(p, reinterpret_cast<hipfftComplex *>(in), out) != HIPFFT_SUCCESS) return SP3D_EFFT;
@@ -82,7 +102,7 @@ extern "C" int sp3d_cfft2d(float *data, int batch, int SX, int SY, int inverse, 
     int rc = check_args(data, data, batch, SX, SY, 1);
     if (rc) return rc;
     hipfftHandle p;
-    if ((rc = get_plan(2, batch, SX, SY, 0, &p))) return rc;
+    if ((rc = get_plan(2, batch, SX, SY, 0, stream, &p))) return rc;
     std::lock_guard<std::mutex> lock(g_mu);
     if (hipfftSetStream(p, (hipStream_t)stream) != HIPFFT_SUCCESS) return SP3D_EFFT;
     hipfftComplex *d = reinterpret_cast<hipfftComplex *>(data);

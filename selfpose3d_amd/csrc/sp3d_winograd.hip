@@ -1306,7 +1306,11 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
     const unsigned *w3 = reinterpret_cast<const unsigned *>(W3), *xs3 = reinterpret_cast<const unsigned *>(xs);
     unsigned *ys3 = reinterpret_cast<unsigned *>(ys);
     const int out = (y ? 1 : 0) | (ys ? 2 : 0);
-#define SP3D_CD(C_, M_, I_, O_) { static bool attr = false; if (!attr) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
+    // the attribute is per device: remember it per device (a process that drives several GPUs launches on each)
+    int cd_dev = 0;
+    { const hipError_t ed = hipGetDevice(&cd_dev); if (ed != hipSuccess) return (int)ed; }
+    if (cd_dev < 0 || cd_dev >= 64) cd_dev = 63;
+#define SP3D_CD(C_, M_, I_, O_) { static bool attr_dev[64] = {}; bool &attr = attr_dev[cd_dev]; if (!attr || cd_dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
     hipLaunchKernelGGL((conv3_split_kernel<C_, M_, I_, O_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks, xs3, ys3); }
 #define SP3D_CDO(C_, M_, I_) { if (out == 1) SP3D_CD(C_, M_, I_, 1) else if (out == 2) SP3D_CD(C_, M_, I_, 2) else SP3D_CD(C_, M_, I_, 3) }
 #define SP3D_CDI(C_, I_) switch (mode) { case 0: SP3D_CD(C_, 0, I_, 1); break; case 1: SP3D_CDO(C_, 1, I_); break; case 2: SP3D_CDO(C_, 2, I_); break; default: SP3D_CD(C_, 3, I_, 1); }

@@ -126,17 +126,15 @@ def rank_generator(base_seed: int, rank: int | None = None) -> torch.Generator:
 
 
 def needs_find_unused(cfg) -> bool:
-    """Does the stage this config trains leave parameters of the wrapped model without gradients?  (DDP then has to
-    walk the autograd graph every step.)  Follows the stage flags of the reference's tools/train_3d.py:48-75: frozen
-    sub-nets have requires_grad=False and are no problem; parameters that REQUIRE grad but are not reached are -
-    the root net when proposals come from ground truth (USE_GT) and the 3D nets in a 2D-only stage are simply not
-    constructed / not called, and the pose net is skipped on iterations without a valid proposal."""
-    net = cfg.NETWORK
-    if net.get("TRAIN_ONLY_2D", False):
-        return False                     # only the backbone exists and it is always reached
-    if net.get("TRAIN_ONLY_ROOTNET", False):
-        return False                     # pose net frozen, root net always reached
-    return True                          # pose net trains: an iteration without valid proposals reaches none of it
+    """Does DDP have to search for parameters without gradients every step (find_unused_parameters)?  No: every
+    parameter that requires grad gets one on every rank in every iteration, by construction -
+    * frozen sub-nets have requires_grad=False (tools/train_3d.py select_trainable, following the reference's
+      tools/train_3d.py:48-75; this includes the root net when proposals come from ground truth, USE_GT);
+    * a sub-net that trains but is skipped in an iteration (the pose net when a rank's frames hold no valid proposal)
+      is tied to the loss with zero weight inside the model's forward (engine.zero_anchor), as the reference does with
+      zero-weighted dummy forwards (lib/models/multi_person_posenet_ssv.py:290,429,496,499).
+    So the static-graph fast path of DDP applies, and no rank can skip backward() (which would hang the others)."""
+    return False
 
 
 def wrap_ddp(model: torch.nn.Module, device: torch.device | None = None, find_unused: bool = True):

@@ -33,6 +33,18 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
+def zero_anchor(params):
+    """0 * (first element of every trainable parameter): added to a loss it makes EVERY trainable parameter part of
+    the autograd graph with an exactly-zero gradient contribution.  DistributedDataParallel's gradient all-reduce is a
+    collective: a rank whose loss reached no parameter (no valid proposal in its frames) must still run backward() with
+    every bucket, or the other ranks wait forever.  The reference gets the same effect from zero-weighted dummy forwards
+    (lib/models/multi_person_posenet_ssv.py:290,429,496,499).  None when nothing is trainable."""
+    ps = [p for p in params if p.requires_grad]
+    if not ps:
+        return None
+    return torch.cat([p.reshape(-1)[:1] for p in ps]).sum() * 0.0
+
+
 def _to_device(x, dev):
     if isinstance(x, torch.Tensor):
         return x.to(dev, non_blocking=True)
@@ -66,6 +78,12 @@ def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_di
             loss = loss_2d + loss_3d + loss_cord                                  # function.py:279
         losses.update(loss.item())
         optimizer.zero_grad(set_to_none=True)
+        if not loss.requires_grad:
+            # nothing trainable was reached on THIS rank: backward() must run all the same (see zero_anchor); the models
+            # anchor their own skipped sub-nets inside forward, this is the last line of defence
+            anchor = zero_anchor(net.parameters())
+            if anchor is not None:
+                loss = loss + anchor
         if loss.requires_grad:
             loss.backward()
             optimizer.step()
@@ -86,6 +104,56 @@ def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_di
                 writer_dict["train_global_steps"] = g + 1
     return {"loss": losses.avg, "loss_2d": l2d.avg, "loss_3d": l3d.avg, "loss_cord": lcord.avg,
             "batch_time": bt.avg}
+
+
+SSV_LOSS_KEYS = ("loss_2d", "loss_root_reg", "loss_root_syn", "loss_pose3d_ssv", "loss_attn_ssv", "loss_pose3d_l1_ssv")
+
+
+def train_3d_ssv(config, model, optimizer, loader, epoch, output_dir=None, writer_dict=None, device=None, max_iters=None):
+    """self-supervised loop (/root/reference/lib/core/function.py:27-217): three view sets per frame, a dict of loss
+    terms, total = sum of the terms that require grad (:107)"""
+    net = _unwrap(model)
+    device = device or next(net.parameters()).device
+    bt, dt = AverageMeter(), AverageMeter()
+    meters = {k: AverageMeter() for k in SSV_LOSS_KEYS + ("losses",)}
+    model.train()
+    if not config.NETWORK.TRAIN_BACKBONE and net.backbone is not None:
+        net.backbone.eval()                                                     # function.py:43-45
+    if config.NETWORK.get("FREEZE_ROOTNET", False) and getattr(net, "root_net", None) is not None:
+        net.root_net.eval()                                                     # :46-48
+    end = time.time()
+    for i, batch in enumerate(loader):
+        if max_iters is not None and i >= max_iters:
+            break
+        dt.update(time.time() - end)
+        (in1, t2d1, w2d1, t3d1, meta1, _, in2, t2d2, w2d2, t3d2, meta2, _, in3, t2d3, w2d3, t3d3, meta3, _) = batch
+        in1, in2, in3 = (_to_device(x, device) for x in (in1, in2, in3))
+        _, _, _, loss_dict = model(views1=in1, meta1=meta1, targets_2d1=t2d1, weights_2d1=w2d1, targets_3d1=t3d1[0],
+                                   views2=in2, meta2=meta2, targets_2d2=t2d2, weights_2d2=w2d2, targets_3d2=t3d2[0],
+                                   views3=in3, meta3=meta3, targets_2d3=t2d3, weights_2d3=w2d3, targets_3d3=t3d3[0],
+                                   epoch=epoch)
+        terms = [v.mean() for v in loss_dict.values() if v.requires_grad]        # :107
+        for k, v in loss_dict.items():
+            meters[k].update(float(v.mean()))
+        optimizer.zero_grad(set_to_none=True)
+        if not terms:                                                            # every rank must run backward (zero_anchor)
+            anchor = zero_anchor(net.parameters())
+            terms = [] if anchor is None else [anchor]
+        if terms:
+            loss = sum(terms)
+            meters["losses"].update(loss.item())
+            loss.backward()
+            optimizer.step()
+        bt.update(time.time() - end)
+        end = time.time()
+        if i % int(config.PRINT_FREQ) == 0:
+            V, B = len(in1), in1[0].size(0)
+            logger.info(f"Epoch: [{epoch}][{i}/{len(loader)}]\tTime: {bt.val:.3f}s ({bt.avg:.3f}s)\t"
+                        f"Speed: {V * B / max(bt.val, 1e-9):.1f} samples/s\tData: {dt.val:.3f}s\t" +
+                        "\t".join(f"{k}: {m.val:.6f} ({m.avg:.6f})" for k, m in meters.items()))
+    out = {k: m.avg for k, m in meters.items()}
+    out["batch_time"] = bt.avg
+    return out
 
 
 @torch.no_grad()

@@ -104,6 +104,14 @@ class MultiPersonPoseNet(nn.Module):
                     count += 1
                     term = self.l1(single[i:i + 1], gt_3d[i:i + 1, g], True, vis[i:i + 1, g, :, 0:1])
                     loss_cord = (loss_cord * (count - 1) + term) / count
+        if count == 0:
+            # no valid proposal (or no ground truth) in this rank's frames: the pose net's parameters must still be in
+            # the graph of the losses, with zero weight, so that every DDP rank runs the same gradient all-reduce
+            # (engine.zero_anchor; the reference's zero-weighted dummy forwards, multi_person_posenet_ssv.py:290,429)
+            from .engine import zero_anchor
+            anchor = zero_anchor(self.pose_net.parameters())
+            if anchor is not None:
+                loss_cord = loss_cord + anchor
         return pred, all_heatmaps, grid_centers, loss_2d, loss_3d, loss_cord
 
 

@@ -1,16 +1,23 @@
-"""Self-supervised top-level model (``MODEL: multi_person_posenet_ssv``), INFERENCE path.
+"""Self-supervised top-level model (``MODEL: multi_person_posenet_ssv``): inference and the training forward.
 
-Interface, return tuple and state_dict prefixes (``backbone.``, ``attn.``, ``pose_net.``, ``root_net.``)
-follow /root/reference/lib/models/multi_person_posenet_ssv.py:29-153: ``do_inference`` = backbone per view
--> ``CuboidProposalNetSoft`` (HIP unprojection, V2V, fused NMS/top-k) -> pose net on every valid proposal.
-As in ``MultiPersonPoseNet`` the views run through the backbone as one batch and all proposals are
-unprojected in ONE launch and regressed in batched V2V calls (the reference loops over MAX_PEOPLE_NUM
-candidates, :142-148); in eval mode the results are the loop's.
+Interface, return tuples, loss-dict keys and state_dict prefixes (``backbone.``, ``attn.``, ``pose_net.``,
+``root_net.``) follow /root/reference/lib/models/multi_person_posenet_ssv.py:29-501.
 
-The SSV *training* forward (two augmented passes, Hungarian matching, differentiable re-rendering,
-:197-501) is NOT built: calling ``forward`` without ``inference=True`` raises instead of silently
-training something else.  Its kernels exist separately (``reprojection.py``, ``sp3d_render_joints_*``,
-``CuboidProposalNetSoft.train_rootnet``).
+``do_inference`` (:105-153) = backbone per view -> ``CuboidProposalNetSoft`` (HIP unprojection, V2V, fused NMS/top-k) ->
+pose net on every valid proposal; the views run through the backbone as one batch and all proposals are unprojected
+in ONE launch and regressed in batched V2V calls (the reference loops over MAX_PEOPLE_NUM candidates, :142-148).
+
+``forward`` without ``inference`` is the self-supervised training step (:197-501), assembled from the pieces this repo
+already has: three view sets (two affine-augmented, one plain) -> heat-maps (+ attention maps) -> root net on set 3
+(frozen stage) or on all three with the synthetic-root branch (root-net stage) -> pose net on sets 1 and 2 for every
+valid proposal -> each set's poses re-projected into the OTHER set's crops (``reprojection.project_joints`` ==
+``cameras.project_pose_batch``) and rendered as Gaussian heat-maps by the HIP kernel pair ``sp3d_render_joints_fwd/bwd``
+(differentiable; the reference builds (P,J,h,w) temporaries per view and sample in Python loops, :409-465) -> attention-
+weighted MSE against the pseudo-label maps, attention regulariser, optional Hungarian L1 term (:155-194).
+Deliberate differences, both value-neutral: the reference keeps parameters in the autograd graph with zero-weighted
+DUMMY FORWARDS (a (1,3,512,960) backbone pass, :290; a zero cube through the pose net's V2V, :429,496,499); here the same
+zero-valued terms come from ``engine.zero_anchor`` (no extra convolutions).  Datasets, RandAugment and the evaluation
+code of the SSL pipeline are out of scope; ``synthetic_dataset.SyntheticPanopticSSV`` feeds the loop.
 """
 from __future__ import annotations
 
@@ -31,6 +38,20 @@ class MultiPersonPoseNetSSV(nn.Module):
         self.WITH_ATTN = bool(cfg.get("WITH_ATTN", False))
         if self.WITH_ATTN:
             self.attn = attn
+        self.attn_weight = float(cfg.get("ATTN_WEIGHT", 0.1))
+        self.USE_L1 = bool(cfg.get("USE_L1", False))
+        self.L1_WEIGHT = float(cfg.get("L1_WEIGHT", 0.1))
+        self.L1_ATTN = bool(cfg.get("L1_ATTN", False))
+        self.L1_EPOCH = int(cfg.TRAIN.get("L1_EPOCH", 5)) if "TRAIN" in cfg else 5
+        self.width, self.height = int(cfg.NETWORK.IMAGE_SIZE[0]), int(cfg.NETWORK.IMAGE_SIZE[1])
+        self.heatmap_width, self.heatmap_height = int(cfg.NETWORK.HEATMAP_SIZE[0]), int(cfg.NETWORK.HEATMAP_SIZE[1])
+        self.rootnet_train_synth = bool(cfg.NETWORK.get("ROOTNET_TRAIN_SYNTH", False))
+        self.freeze_rootnet = bool(cfg.NETWORK.get("FREEZE_ROOTNET", False))
+        self.single_aug_training_posenet = bool(cfg.NETWORK.get("SINGLE_AUG_TRAINING_POSENET", False))
+        self.root_reg_loss = bool(cfg.NETWORK.get("ROOT_CONSISTENCY_LOSS", True))
+        self.weight_root_syn = float(cfg.NETWORK.get("WEIGHT_ROOT_SYN", 100.0))
+        self.weight_root_reg = float(cfg.NETWORK.get("WEIGHT_ROOT_REG", 1.0))
+        self.init_train_epochs_rootnet = int(cfg.NETWORK.get("INIT_TRAIN_EPOCHS_ROOTNET", 0))
         self.use_root_gt = bool(cfg.NETWORK.USE_GT)
         self.train_only_2d = bool(cfg.NETWORK.TRAIN_ONLY_2D)
         self.train_only_rootnet = bool(cfg.NETWORK.get("TRAIN_ONLY_ROOTNET", False))
@@ -91,6 +112,51 @@ class MultiPersonPoseNetSSV(nn.Module):
             return pred, all_heatmaps, grid_centers, attns
         return pred, all_heatmaps, grid_centers
 
+    # -- training forward ------------------------------------------------------------------------------------
+    def l1_matching_loss(self, kps, count, meta):
+        """Hungarian-matched mean |pred - pseudo-GT| of the re-projected 2D joints, per (view, sample)
+        (multi_person_posenet_ssv.py:155-194).  kps (V,B,P,J,2) network-input pixels, count (B,) valid poses.
+        (The reference normalises ``meta[...]['joints']`` and the predictions IN PLACE; here the same quotients are
+        formed out of place.)"""
+        from scipy.optimize import linear_sum_assignment
+        V, B = kps.shape[:2]
+        dev = kps.device
+        size = torch.tensor([float(self.width), float(self.height)], device=dev)
+        losses = torch.zeros(V * B, device=dev)
+        for nv in range(V):
+            joints = meta[nv]["joints"].to(dev, torch.float32)
+            vis = meta[nv]["joints_vis"].to(dev, torch.float32)
+            for bs in range(B):
+                num_gt = int((joints[bs].sum(-1).sum(-1) != 0).sum())
+                num_pred = int(count[bs])
+                if num_pred == 0 or num_gt == 0:
+                    continue
+                target = joints[bs, :num_gt] / size
+                pred = kps[nv, bs, :num_pred] / size
+                d = ((pred[None] - target[:, None]) * vis[bs, :num_gt, None]).abs().mean(dim=(-1, -2))   # (gt, pred)
+                mx, my = linear_sum_assignment(d.detach().cpu().numpy())
+                losses[nv * B + bs] = d[torch.as_tensor(mx, device=dev), torch.as_tensor(my, device=dev)].sum()
+        if self.L1_ATTN:                                                     # drop the worst (view, sample) (:188-191)
+            mask = torch.ones(V * B, device=dev)
+            mask[torch.argmax(losses)] = 0.0
+            return (losses * mask).sum() / (B * V - 1)
+        return losses.mean()
+
+    def _pose_pass(self, heatmaps, meta, grid_centers, flip):
+        """pose net on every candidate that has a valid proposal in some sample (:361-381): (B, num_cand, J, 5)"""
+        B = grid_centers.shape[0]
+        pred = torch.zeros(B, self.num_cand, self.num_joints, 5, device=grid_centers.device)
+        pred[:, :, :, 3:] = grid_centers[:, :, 3:].reshape(B, -1, 1, 2)
+        flags = grid_centers[:, :, 3].detach().cpu()
+        for n in range(self.num_cand):
+            if bool((flags[:, n] >= 0).any()):
+                pred[:, n, :, 0:3] = self.pose_net(heatmaps, meta, grid_centers[:, n], flip_xcoords=flip)
+        return pred
+
+    def _reprojection_maps(self, pred, count, cam, trans):
+        from .reprojection import project_joints, reprojection_heatmaps
+        return reprojection_heatmaps(pred[..., :3], count, cam, self.heatmap_height, self.heatmap_width, 4.0, 3.0, trans)
+
     def forward(self, views1=None, meta1=None, targets_2d1=None, weights_2d1=None, targets_3d1=None, input_heatmaps1=None,
                 views2=None, meta2=None, targets_2d2=None, weights_2d2=None, targets_3d2=None, input_heatmaps2=None,
                 views3=None, meta3=None, targets_2d3=None, weights_2d3=None, targets_3d3=None, input_heatmaps3=None,
@@ -98,11 +164,120 @@ class MultiPersonPoseNetSSV(nn.Module):
         if inference:                                                            # :221-222
             return self.do_inference(views=views1, meta=meta1, input_heatmaps=input_heatmaps1,
                                      visualize_attn=visualize_attn)
-        raise NotImplementedError(
-            "MultiPersonPoseNetSSV: only the inference path (forward(..., inference=True) / do_inference) is built; "
-            "the self-supervised training forward of the reference (multi_person_posenet_ssv.py:197-501) is out of "
-            "this repo's hot-path scope.  Train the supervised model (MODEL: multi_person_posenet) or call "
-            "CuboidProposalNetSoft / reprojection.render_* directly.")
+        import torch.nn.functional as F
+        from .engine import zero_anchor
+        hm3 = self._heatmaps(views3, input_heatmaps3)                             # set 3: no augmentation (:226-232)
+        attns1 = attns2 = None
+        if self.WITH_ATTN:                                                       # :234-244
+            if views1 is not None:
+                attns1 = torch.stack([self.attn(v) for v in views1], 0)
+            if views2 is not None:
+                attns2 = torch.stack([self.attn(v) for v in views2], 0)
+        hm1 = self._heatmaps(views1, input_heatmaps1)
+        hm2 = self._heatmaps(views2, input_heatmaps2)
+        device = hm1[0].device
+        B = hm1[0].shape[0]
+        zero = torch.zeros((), device=device)
+
+        def anchored(module):        # the value of the reference's zero-weighted dummy forwards, without running them
+            a = zero_anchor(module.parameters()) if module is not None else None
+            return zero.clone() if a is None else a
+
+        losses = {}
+        if targets_2d1 is not None and targets_2d2 is not None:                  # :281-288
+            t1 = torch.stack([t.to(device) for t in targets_2d1])
+            t2 = torch.stack([t.to(device) for t in targets_2d2])
+            t3 = torch.stack([t.to(device) for t in targets_2d3])
+            losses["loss_2d"] = (F.mse_loss(t1, torch.stack(list(hm1))) + F.mse_loss(t2, torch.stack(list(hm2))) +
+                                 F.mse_loss(t3, torch.stack(list(hm3)))) / 3.0
+        else:
+            t1 = t2 = None
+            losses["loss_2d"] = anchored(self.backbone)                           # :290
+        if self.train_only_2d:
+            return None, hm3, None, losses
+
+        flip1 = meta1[0].get("hflip") if meta1 is not None else None
+        flip2 = meta2[0].get("hflip") if meta2 is not None else None
+        flip3 = meta3[0].get("hflip") if meta3 is not None else None
+        if self.use_root_gt:                                                     # :297-304
+            num_person = meta3[0]["num_person"]
+            grid_centers = torch.zeros(B, self.num_cand, 5, device=device)
+            grid_centers[:, :, 0:3] = meta3[0]["roots_3d"].float().to(device)
+            grid_centers[:, :, 3] = -1.0
+            for i in range(B):
+                n = int(num_person[i])
+                grid_centers[i, :n, 3] = torch.arange(n, device=device, dtype=torch.float32)
+                grid_centers[i, :n, 4] = 1.0
+        elif self.freeze_rootnet:                                                # :306-307
+            # nothing differentiable comes out of a frozen root net (proposal indices, flags, scores that only travel
+            # into the returned pred[..., 3:]): run it without a graph - in eval mode that is the fused inference plan
+            with torch.no_grad():
+                _, _, _, grid_centers = self.root_net([h.detach() for h in hm3], meta3, flip_xcoords=flip3)
+        elif self.rootnet_train_synth:                                           # :309-330
+            main1, syn1, tgt1, _ = self.root_net(hm1, meta1, flip_xcoords=flip1)
+            main2, syn2, tgt2, _ = self.root_net(hm2, meta2, flip_xcoords=flip2)
+            main3, syn3, tgt3, grid_centers = self.root_net(hm3, meta3, flip_xcoords=flip3)
+            losses["loss_root_syn"] = self.weight_root_syn * (F.mse_loss(syn1, tgt1) + F.mse_loss(syn2, tgt2) +
+                                                              F.mse_loss(syn3, tgt3))
+            main3 = main3.detach()
+            if self.root_reg_loss:
+                losses["loss_root_reg"] = self.weight_root_reg * (F.mse_loss(main1, main3) + F.mse_loss(main2, main3))
+        else:                                                                    # :331-335
+            rc1, _, _, _ = self.root_net(hm1, meta1, flip_xcoords=flip1)
+            rc2, _, _, _ = self.root_net(hm2, meta2, flip_xcoords=flip2)
+            _, _, _, grid_centers = self.root_net(hm3, meta3, flip_xcoords=flip3)
+            losses["loss_root_reg"] = F.mse_loss(rc1, targets_3d1.to(device)) + F.mse_loss(rc2, targets_3d2.to(device))
+        if self.train_only_rootnet:
+            return None, hm3, grid_centers, losses
+
+        if epoch < self.init_train_epochs_rootnet:                               # :497-499
+            losses["loss_pose3d_ssv"] = anchored(self.pose_net)
+            return None, hm3, grid_centers, losses
+
+        from .camera_pack import pack_cameras
+        count = (grid_centers[:, :, 3] >= 0).sum(1)                              # valid proposals lead the list (:386)
+        pred1 = self._pose_pass(hm1, meta1, grid_centers, flip1)
+        cam = torch.from_numpy(pack_cameras(meta1, B, [self.width, self.height])).to(device)   # proj_cameras (:397)
+        trans1 = meta1[0]["trans"]
+        have_people = int(count[0]) > 0              # the reference tests sample 0 only (pred1[0].shape[0] > 0, :409,433)
+        if self.single_aug_training_posenet:                                     # :409-429
+            pred_out = pred1.detach().clone()
+            if have_people:
+                maps11 = self._reprojection_maps(pred1, count, cam, trans1)
+                losses["loss_pose3d_ssv"] = F.mse_loss(t1, maps11) if t1 is not None else zero.clone()
+            else:
+                losses["loss_pose3d_ssv"] = anchored(self.pose_net)
+            return pred_out, hm3, grid_centers, losses
+
+        pred2 = self._pose_pass(hm2, meta2, grid_centers, flip2)
+        pred_out = pred2.detach().clone()
+        trans2 = meta2[0]["trans"]
+        if have_people:                                                          # :433-486
+            from .reprojection import project_joints
+            maps21 = self._reprojection_maps(pred2, count, cam, trans1)           # set 2's poses in set 1's crops
+            maps12 = self._reprojection_maps(pred1, count, cam, trans2)           # set 1's poses in set 2's crops
+            l1 = l2 = zero.clone()
+            if t1 is not None:
+                l1 = (F.mse_loss(t1, maps21, reduction="none") * attns1).mean() if self.WITH_ATTN else F.mse_loss(t1, maps21)
+            if t2 is not None:
+                l2 = (F.mse_loss(t2, maps12, reduction="none") * attns2).mean() if self.WITH_ATTN else F.mse_loss(t2, maps12)
+            losses["loss_pose3d_ssv"] = l1 + l2
+            if self.WITH_ATTN:
+                losses["loss_attn_ssv"] = (F.mse_loss(attns1, torch.ones_like(attns1)) +
+                                           F.mse_loss(attns2, torch.ones_like(attns2))) * self.attn_weight
+            if self.USE_L1 and epoch >= self.L1_EPOCH:
+                kps12 = project_joints(pred1[..., :3], cam, 1.0, trans2)          # network-input pixels (V,B,P,J,2)
+                kps21 = project_joints(pred2[..., :3], cam, 1.0, trans1)
+                losses["loss_pose3d_l1_ssv"] = (self.l1_matching_loss(kps12, count, meta2) +
+                                                self.l1_matching_loss(kps21, count, meta1)) * self.L1_WEIGHT
+        else:                                                                    # :487-495
+            if self.WITH_ATTN:
+                losses["loss_attn_ssv"] = (F.mse_loss(attns1, torch.ones_like(attns1)) +
+                                           F.mse_loss(attns2, torch.ones_like(attns2))) * 0.0
+            if self.USE_L1 and epoch >= self.L1_EPOCH:
+                losses["loss_pose3d_l1_ssv"] = zero.clone()
+            losses["loss_pose3d_ssv"] = anchored(self.pose_net)
+        return pred_out, hm3, grid_centers, losses
 
 
 def get_multi_person_pose_net(cfg, is_train: bool = True):

@@ -94,6 +94,9 @@ def make_meta(batch: int, num_views: int, image_size: Sequence[int],
             "k": torch.as_tensor(np.repeat(cam["k"][None], batch, 0), dtype=cdt),
             "p": torch.as_tensor(np.repeat(cam["p"][None], batch, 0), dtype=cdt),
         }
+        if ssv_style:                                          # JointsDatasetSSV.py:230-237 also stores the pairs
+            camera["f"] = torch.stack([camera["fx"], camera["fy"]], -1).reshape(batch, 2, 1)
+            camera["c"] = torch.stack([camera["cx"], camera["cy"]], -1).reshape(batch, 2, 1)
         center = torch.tensor([[ORIG_IMAGE[0] / 2.0, ORIG_IMAGE[1] / 2.0]] * batch, dtype=torch.float64)
         scale = np.repeat(base_scale[None], batch, 0).copy()
         if scale_mults is not None:

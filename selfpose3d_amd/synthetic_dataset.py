@@ -104,3 +104,62 @@ class SyntheticPanoptic(Dataset):
                 "camera": {k: (np.asarray(val)) for k, val in cam.items()},
             })
         return inputs, targets, weights, t3ds, metas, ihm
+
+
+class SyntheticPanopticSSV(SyntheticPanoptic):
+    """The 18-tuple the reference's self-supervised loop consumes (lib/core/function.py:50-69; sample schema of
+    lib/dataset/JointsDatasetSSV.py:540-587): the same frame as THREE view sets - two under independent random crop
+    rotation / scale (``DATASET.ROT_FACTOR1/2`` degrees, ``SCALE_FACTOR1/2``), one plain - each as
+    (inputs, target_heatmaps, target_weights, targets_3d, meta, input_heatmaps).  The target heat-maps play the role of
+    the pseudo labels (here: Gaussians of the projected ground-truth joints under that set's crop); ``meta`` carries the
+    SSV extras: fp32 camera tensors incl. ``f`` / ``c``, the crop affine ``trans``, ``hflip`` (always False here),
+    the 2D pseudo-label joints ``joints`` / ``joints_vis`` in network-input pixels.  RandAugment / cut-out act on image
+    CONTENT only and are not modelled (the images are noise)."""
+
+    def _set(self, idx, joints, rot, mult):
+        from .camera_pack import get_affine_transform_batch
+        w, h = self.hm
+        sigma = float(self.cfg.NETWORK.SIGMA)
+        P = joints.shape[0]
+        center = np.array([syn.ORIG_IMAGE[0] / 2.0, syn.ORIG_IMAGE[1] / 2.0])
+        scale = (self.scale * np.float32(mult)).astype(np.float32)
+        trans = get_affine_transform_batch(center[None], scale[None], np.array([rot], np.float64), self.img)[0]
+        j3d = np.zeros((self.maxp, self.J, 3)); j3d[:P] = joints
+        vis3 = np.zeros((self.maxp, self.J, 3)); vis3[:P] = 1.0
+        roots = j3d[:, self.root_id]
+        t3d = torch.from_numpy(self._target_3d(roots[:P]))
+        xs, ys = np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64)
+        stride = np.array([self.img[0] / w, self.img[1] / h])
+        inputs, targets, weights, t3ds, metas, ihm = [], [], [], [], [], []
+        for v, cam in enumerate(self.cams):
+            px = syn._project_f64(joints.reshape(-1, 3), cam).reshape(P, self.J, 2)
+            q = px @ trans[:, :2].T + trans[:, 2]                              # network-input pixels
+            qq = q / stride
+            gx = np.exp(-((xs[None, None, :] - qq[..., 0:1]) ** 2) / (2 * sigma ** 2))
+            gy = np.exp(-((ys[None, None, :] - qq[..., 1:2]) ** 2) / (2 * sigma ** 2))
+            hm = torch.from_numpy(np.clip((gy[..., :, None] * gx[..., None, :]).max(axis=0), 0, 1).astype(np.float32))
+            j2d = np.zeros((self.maxp, self.J, 2), np.float32); j2d[:P] = q
+            v2d = np.zeros((self.maxp, self.J, 2), np.float32); v2d[:P] = 1.0
+            camera = {k: np.asarray(val, np.float32) for k, val in cam.items()}
+            camera["f"] = np.array([[cam["fx"]], [cam["fy"]]], np.float32)
+            camera["c"] = np.array([[cam["cx"]], [cam["cy"]]], np.float32)
+            inputs.append(self._image(idx, v) if self.images else torch.zeros(3, 1, 1))
+            targets.append(hm); weights.append(torch.ones(self.J, 1)); t3ds.append(t3d); ihm.append(hm)
+            metas.append({"image": f"synthetic/{idx:06d}_{v}", "num_person": P, "joints_3d": j3d, "joints_3d_vis": vis3,
+                          "roots_3d": roots, "center": center.copy(), "scale": scale.copy(), "rotation": float(rot),
+                          "camera": camera, "trans": trans.astype(np.float32), "hflip": False,
+                          "joints": j2d, "joints_vis": v2d, "mis_count": 0})
+        return inputs, targets, weights, t3ds, metas, ihm
+
+    def __getitem__(self, idx):
+        ds = self.cfg.DATASET
+        rng = np.random.default_rng(self.seed * 7919 + idx)
+        pts = syn.people_points(1, self.J, self.seed * 100003 + idx)
+        joints = pts[0][:self.max_people]
+        out = ()
+        for k in (1, 2):
+            rf, sf = float(ds.get(f"ROT_FACTOR{k}", 45)), float(ds.get(f"SCALE_FACTOR{k}", 0.35))
+            rot = float(np.clip(rng.standard_normal() * rf, -2 * rf, 2 * rf)) if rng.random() < 0.6 else 0.0
+            mult = float(np.clip(rng.standard_normal() * sf + 1.0, 1 - sf, 1 + sf))
+            out = out + self._set(idx, joints, rot, mult)
+        return out + self._set(idx, joints, 0.0, 1.0)

@@ -409,6 +409,17 @@ class _FoldedV2V:
         view._sp3d_fft_shape = S
         return view
 
+    def _is_padded_view(self, x, cin, S):
+        """is x the [:X,:Y,:Z] corner of whole samples of the zero-padded buffer this plan owns for (cin, S)?"""
+        buf = self.t.get(("xpad", cin, S, str(x.device)))
+        vol = S[0] * S[1] * S[2]
+        if buf is None or x.dim() != 5 or x.shape[1] != cin or x.dtype != buf.dtype or \
+                tuple(x.stride()) != (cin * vol, vol, S[1] * S[2], S[2], 1):
+            return False
+        off = x.data_ptr() - buf.data_ptr()
+        per = cin * vol * buf.element_size()
+        return off >= 0 and off % per == 0 and off // per + x.shape[0] <= buf.shape[0]
+
     def _front_fft(self, x, w0, s0):
         """the 7x7x7 opening conv in the frequency domain: zero-padded rFFT (rocFFT via torch.fft) ->
         sp3d_freq_contract -> irFFT -> crop + shift + ReLU.  3.3x (80x80x20, B=4) to 4.7x (64^3) faster than the
@@ -438,9 +449,10 @@ class _FoldedV2V:
             Xs = _lib.cfft2d_(_lib.zdft_fwd_cl(x, cin, S), False, rows_in=X)          # rows x >= X are zero padding
             Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self.t[zkey]), True, rows_out=X)   # ... and not read on the way back
             return _lib.zdft_inv_cl(Ys, X, Y, Z, S[2], s0, True)
-        if getattr(x, "_sp3d_fft_shape", None) == S and x.shape[1] == cin and \
-                x.stride() == (x.stride(0), S[0] * S[1] * S[2], S[1] * S[2], S[2], 1):
-            # x IS the signal corner of a zero-padded buffer (fft_input_view / fft_input_views): no pad/copy pass
+        if self._is_padded_view(x, cin, S):
+            # x IS the signal corner of this plan's zero-padded buffer (fft_input_view / input_chunk_views): no pad/copy
+            # pass.  Recognised by address and strides, not by a Python attribute: a tensor that went through an
+            # autograd Function under no_grad comes back as a NEW Python object for the same memory (advisor, round 2)
             buf = x.as_strided((B, cin) + S, x.stride(), x.storage_offset())
         else:
             buf = self._fft_buffer(B, cin, S, x.device)

@@ -63,3 +63,58 @@ SMALL_CASES = ["unproj_coarse_small", "unproj_coarse_j1_v1", "unproj_coarse_aug"
                "unproj_grad_small", "unproj_grad_fine_aug"]
 FULL_CASES = ["unproj_coarse_full_96x72", "unproj_coarse_full_240x128", "unproj_fine_full_240x128",
               "unproj_stress_v10", "unproj_people_coarse"]
+
+
+# ---- round 3: model-level training goldens (tests/golden/make_goldens_r3.py) -----------------------------------------
+TRAIN_SMALL = dict(img=(128, 96), hm=(32, 24), V=3, J=15, cube=(24, 24, 8), fine_cube=(16, 16, 16), max_people=4,
+                   layers=18, threshold=0.0, sigma=3)
+
+
+def train_cfg(ssv=False, **net):
+    """this repo's config for the small training scene (the golden script builds the reference's cfg from TRAIN_SMALL)"""
+    from selfpose3d_amd.config import load_config
+    t = TRAIN_SMALL
+    kw = dict(NETWORK__IMAGE_SIZE=list(t["img"]), NETWORK__HEATMAP_SIZE=list(t["hm"]), NETWORK__NUM_JOINTS=t["J"],
+              NETWORK__SIGMA=t["sigma"], NETWORK__TRAIN_BACKBONE=True, DATASET__CAMERA_NUM=t["V"],
+              POSE_RESNET__NUM_LAYERS=t["layers"], MULTI_PERSON__INITIAL_CUBE_SIZE=list(t["cube"]),
+              MULTI_PERSON__MAX_PEOPLE_NUM=t["max_people"], MULTI_PERSON__THRESHOLD=t["threshold"],
+              PICT_STRUCT__CUBE_SIZE=list(t["fine_cube"]), TRAIN__BATCH_SIZE=2)
+    if ssv:
+        kw.update(MODEL="multi_person_posenet_ssv", WITH_SSV=True, WITH_ATTN=True, ATTN_WEIGHT=0.1, ATTN_NUM_LAYERS=18,
+                  USE_L1=True, L1_WEIGHT=0.01, L1_ATTN=True, TRAIN__L1_EPOCH=0, NETWORK__ROOTNET_ROOTHM=True,
+                  NETWORK__ROOTNET_TRAIN_SYNTH=True, NETWORK__FREEZE_ROOTNET=True, DATASET__ROT_FACTOR1=30,
+                  DATASET__ROT_FACTOR2=30, DATASET__SCALE_FACTOR1=0.25, DATASET__SCALE_FACTOR2=0.25)
+    for k, v in net.items():
+        kw["NETWORK__" + k] = v
+    return load_config(None, **kw)
+
+
+def train_batch(cfg, B=2, seed=5, ssv=False):
+    """a collated batch of the synthetic (SSV) dataset - the exact inputs of the training goldens"""
+    from torch.utils.data import default_collate
+    from selfpose3d_amd.synthetic_dataset import SyntheticPanoptic, SyntheticPanopticSSV
+    ds = (SyntheticPanopticSSV if ssv else SyntheticPanoptic)(cfg, num_frames=B, seed=seed, max_people=3)
+    return default_collate([ds[i] for i in range(B)])
+
+
+def he_fill(model, seed):
+    """deterministic, depth-safe parameter fill keyed by sorted state_dict names (same keys in the reference and here):
+    He-scaled conv / linear weights, BatchNorm gamma ~ 1, running_var >= 1, small biases / means"""
+    rng = np.random.default_rng(seed)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            t = sd[k]
+            if not torch.is_floating_point(t):
+                continue
+            if t.dim() >= 4:
+                fan = int(np.prod(t.shape[1:]))
+                a = rng.standard_normal(tuple(t.shape)).astype(np.float32) * np.sqrt(2.0 / fan)
+            elif k.endswith("running_var"):
+                a = 1.0 + 0.1 * np.abs(rng.standard_normal(tuple(t.shape))).astype(np.float32)
+            elif k.endswith("weight"):
+                a = 1.0 + 0.05 * rng.standard_normal(tuple(t.shape)).astype(np.float32)
+            else:
+                a = 0.05 * rng.standard_normal(tuple(t.shape)).astype(np.float32)
+            t.copy_(torch.from_numpy(a))
+    return model

@@ -100,13 +100,91 @@ def test_two_rank_gloo_path():
     assert set(errs) == {0, 1} and max(errs.values()) < 1e-6
 
 
-def test_find_unused_follows_the_stage_flags():
+def test_no_stage_needs_find_unused_parameters():
+    """every trainable parameter gets a gradient on every rank in every iteration by construction (frozen sub-nets do
+    not require grad; skipped sub-nets are zero-anchored inside forward), so DDP's static fast path applies"""
     from selfpose3d_amd import distributed as D
     from selfpose3d_amd.config import load_config
-    assert D.needs_find_unused(load_config(None)) is True                                  # pose-net stage
-    assert D.needs_find_unused(load_config(None, NETWORK__TRAIN_ONLY_2D=True)) is False
-    assert D.needs_find_unused(load_config(None, NETWORK__TRAIN_ONLY_ROOTNET=True)) is False
+    for kw in ({}, {"NETWORK__TRAIN_ONLY_2D": True}, {"NETWORK__TRAIN_ONLY_ROOTNET": True}, {"NETWORK__USE_GT": True}):
+        assert D.needs_find_unused(load_config(None, **kw)) is False
     assert D.rank_seed(5, 0) != D.rank_seed(5, 1) and D.rank_seed(5, 1) == D.rank_seed(5, 1)
+
+
+def test_use_gt_freezes_the_unreached_root_net():
+    """with proposals from ground truth the root net is never called; its parameters must not require grad
+    (DDP with find_unused_parameters=False would otherwise raise on the second iteration)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_3d as tool
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.multi_person_posenet import MultiPersonPoseNet
+    cfg = load_config(None, NETWORK__USE_GT=True, MULTI_PERSON__INITIAL_CUBE_SIZE=[8, 8, 4], PICT_STRUCT__CUBE_SIZE=[8, 8, 8])
+    model = MultiPersonPoseNet(None, cfg)
+    params = tool.select_trainable(model, cfg)
+    assert not any(p.requires_grad for p in model.root_net.parameters())
+    assert all(p.requires_grad for p in model.pose_net.parameters()) and len(params) > 0
+
+
+class _StubNet(torch.nn.Module):
+    """stands in for MultiPersonPoseNet in engine.train_3d: on rank `dead_rank` the losses reach no parameter at all
+    (what a batch without a valid proposal does to a frozen-backbone model)"""
+
+    def __init__(self, dead_rank):
+        super().__init__()
+        self.backbone = None
+        self.lin = torch.nn.Linear(3, 1)
+        self.dead_rank = dead_rank
+
+    def forward(self, views=None, meta=None, targets_2d=None, weights_2d=None, targets_3d=None):
+        import torch.distributed as dist
+        x = views[0]
+        z = torch.zeros((), device=x.device)
+        if dist.get_rank() == self.dead_rank:
+            return None, None, None, z, z.clone(), z.clone()
+        return None, None, None, z, z.clone(), self.lin(x).pow(2).mean()
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from selfpose3d_amd import distributed as D
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.engine import train_3d
+    D.init("gloo")
+    cfg = load_config(None, PRINT_FREQ=100)
+    torch.manual_seed(0)
+    net = _StubNet(dead_rank=1)
+    w0 = net.lin.weight.detach().clone()
+    ddp = D.wrap_ddp(net, find_unused=D.needs_find_unused(cfg))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(10 + rank)
+    batches = [([torch.randn(2, 3, generator=g)], None, None, [None], [{}], None) for _ in range(2)]
+    stats = train_3d(cfg, ddp, opt, batches, 0, device=torch.device("cpu"))        # would hang if rank 1 skipped backward()
+    w = [None] * world
+    dist.all_gather_object(w, net.lin.weight.detach().flatten().tolist())
+    q.put((rank, w[0] == w[1], bool((net.lin.weight.detach() - w0).abs().max() > 0), stats["loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_loop_never_skips_backward_on_one_rank():
+    """round-2 review: engine.train_3d skipped backward() when its loss had no grad - under DDP one rank doing so
+    deadlocks the gradient all-reduce.  Two iterations on two ranks, rank 1's loss reaches no parameter: the loop must
+    finish, the replicas must stay identical, and rank 0's gradient (halved by the mean) must have moved the weights."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "train_3d hung or failed under DDP"
+    res = [q.get(timeout=10) for _ in range(world)]
+    assert all(r[1] for r in res) and all(r[2] for r in res)
+    assert {r[0]: r[3] for r in res}[1] == 0.0
 
 
 def test_single_process_helpers_are_noops():

@@ -33,7 +33,9 @@ def _rootnet_full_inputs(g):
     return img, hm, V, J, hms, syn.make_meta(2, V, img)
 
 
-def _check_root(root_cubes, grid_centers, g, tol=2e-4):
+def _check_root(root_cubes, grid_centers, g, tol=5e-5, cube=None, min_checked=10):
+    # 5e-5 x the output range (+-5.13) = 2.6e-4 absolute: 20x the measured error (1.3e-5); a conv kernel that lost a
+    # decimal digit would fail here (round-2 review: the old 2e-4 would have let a 75x regression through)
     from selfpose3d_amd import synthetic as syn
     rc = root_cubes.float().cpu().numpy()
     N = rc[0].size
@@ -46,7 +48,7 @@ def _check_root(root_cubes, grid_centers, g, tol=2e-4):
     # conv rounding (MIOpen/rocFFT/Winograd vs oneDNN), scores within tol
     vals, idx = g["nms_vals"], g["nms_idx"]
     gc = grid_centers.float().cpu()
-    cs = torch.tensor(syn.INITIAL_CUBE_SIZE, dtype=torch.float32)
+    cs = torch.tensor(syn.INITIAL_CUBE_SIZE if cube is None else cube, dtype=torch.float32)
     gs, cen = torch.tensor(syn.SPACE_SIZE), torch.tensor(syn.SPACE_CENTER)
     checked = 0
     for b in range(2):
@@ -58,7 +60,7 @@ def _check_root(root_cubes, grid_centers, g, tol=2e-4):
                 assert torch.equal(gc[b, k, :3], loc), (b, k)
                 assert abs(float(gc[b, k, 4]) - float(vals[b, k])) <= tol * scale
                 checked += 1
-    assert checked >= 10, checked
+    assert checked >= min_checked, checked
     ref_gc = torch.from_numpy(g["grid_centers"])
     assert torch.equal((gc[:, :, 3] >= 0), (ref_gc[:, :, 3] >= 0))
 

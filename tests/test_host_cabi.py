@@ -291,6 +291,32 @@ def test_v2v_inference_plan_key_sees_every_weight_change():
     net._plan = None
 
 
+def test_padded_fft_input_view_is_recognised_by_address_not_by_python_attribute():
+    """get_voxel(out=view) returns the buffer through an autograd Function; under no_grad that re-wraps the
+    tensor into a new Python object without the old `_sp3d_fft_shape` tag, and the opening conv then copied the padded
+    buffer's corner onto itself.  The plan now recognises its own buffer by data_ptr + strides."""
+    from selfpose3d_amd.v2v_net import V2VNet, _FoldedV2V
+    net = V2VNet(2, 1).eval()
+    plan = _FoldedV2V(net)
+    view = plan.fft_input_view(3, 8, 8, 4, torch.device("cpu"))
+    assert view is not None and tuple(view.shape) == (3, 2, 8, 8, 4)
+    S = plan._fft_shape(8, 8, 4, 7)
+
+    class Fill(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, out):
+            out.fill_(1.0)
+            return out
+
+    with torch.no_grad():
+        back = Fill.apply(view)
+    assert plan._is_padded_view(back, 2, S)                      # same memory, whatever Python object
+    assert plan._is_padded_view(view[1:], 2, S)                  # whole samples further into the buffer
+    assert not plan._is_padded_view(view.clone(), 2, S)          # a copy is not the buffer
+    assert not plan._is_padded_view(view[:, :1], 1, S)           # wrong channel count
+    assert not plan._is_padded_view(view[:, :, 1:], 2, S)        # not the corner
+
+
 def test_three_piece_weight_splits_are_exact_and_laid_out_as_documented():
     """_lib.wino_weights_split / conv_weights_split (host side of the split-product kernels): hi + mid + lo reproduces the
     fp32 weights bit for bit (8+8+8 mantissa bits), pieces are bf16, records follow the layout include/sp3d.h documents"""

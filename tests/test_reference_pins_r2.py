@@ -97,14 +97,22 @@ def test_state_dict_is_the_reference_checkpoint_format(name):
     assert float(model.state_dict()["pose_net.v2v_net.output_layer.weight"].flatten()[0]) == 0.25
 
 
-def test_unknown_model_and_ssv_training_refuse_loudly():
+def test_unknown_model_refuses_loudly_and_ssv_training_has_no_cpu_path():
+    from selfpose3d_amd import _lib
     from selfpose3d_amd.models import get_multi_person_pose_net
     with pytest.raises(ValueError):
         get_multi_person_pose_net(load_config(None, MODEL="multi_person_posenet_xyz"), is_train=False)
-    cfg = load_config(None, MODEL="multi_person_posenet_ssv", BACKBONE_MODEL="", NETWORK__ROOTNET_ROOTHM=True)
+    # round 3: the SSV training forward is built (tests/test_gpu_reference_pins_r3.py pins it to the reference); like
+    # every path through ProjectLayer it has no CPU fallback and says so
+    from tests import golden_io as gio
+    cfg = gio.train_cfg(ssv=True)
+    cfg.BACKBONE_MODEL, cfg.WITH_ATTN = "", False
     model = get_multi_person_pose_net(cfg, is_train=True)
-    with pytest.raises(NotImplementedError):
-        model(views1=None, meta1=None, input_heatmaps1=[torch.zeros(1, 15, 8, 8)])
+    b = gio.train_batch(cfg, B=1, seed=3, ssv=True)
+    hm = [torch.zeros(1, 15, 24, 32) for _ in range(3)]
+    with pytest.raises(_lib.Sp3dError):
+        model(views1=None, meta1=b[4], input_heatmaps1=hm, views2=None, meta2=b[10], input_heatmaps2=hm, views3=None,
+              meta3=b[16], input_heatmaps3=hm)
 
 
 @pytest.mark.parametrize("yaml_name", ["cam5_rootnet.yaml", "cam5_posenet.yaml", "cam5_posenet_finetune.yaml"])

@@ -12,7 +12,7 @@ import torch
 from selfpose3d_amd import distributed as D
 from selfpose3d_amd.config import load_config
 from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
-from selfpose3d_amd.synthetic_dataset import SyntheticPanoptic
+from selfpose3d_amd.synthetic_dataset import SyntheticPanoptic, SyntheticPanopticSSV
 
 
 def setup(cfg_file, phase):
@@ -33,8 +33,8 @@ def setup(cfg_file, phase):
     return cfg, rank, world, device, out
 
 
-def make_loader(cfg, frames, batch_per_gpu, rank, world, seed, shuffle):
-    ds = SyntheticPanoptic(cfg, num_frames=frames, seed=seed)
+def make_loader(cfg, frames, batch_per_gpu, rank, world, seed, shuffle, ssv=False):
+    ds = (SyntheticPanopticSSV if ssv else SyntheticPanoptic)(cfg, num_frames=frames, seed=seed)
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=shuffle) if world > 1 else None
     return torch.utils.data.DataLoader(ds, batch_size=batch_per_gpu, shuffle=(shuffle and sampler is None),
                                        sampler=sampler, num_workers=int(cfg.get("WORKERS", 0)), pin_memory=False,

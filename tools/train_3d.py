@@ -16,7 +16,7 @@ import torch
 
 from _common import load_checkpoint, make_loader, save_checkpoint, setup
 from selfpose3d_amd import distributed as D
-from selfpose3d_amd.engine import train_3d, validate_3d
+from selfpose3d_amd.engine import train_3d, train_3d_ssv, validate_3d
 from selfpose3d_amd.models import get_multi_person_pose_net, is_ssv
 
 logger = logging.getLogger("train_3d")
@@ -29,12 +29,9 @@ def select_trainable(model, cfg):
                 p.requires_grad = flag
     req(model.backbone, bool(cfg.NETWORK.TRAIN_BACKBONE))
     if not cfg.NETWORK.TRAIN_ONLY_2D:
-        if not cfg.NETWORK.TRAIN_ONLY_ROOTNET:
-            req(model.pose_net, True)
-        else:
-            req(model.pose_net, False)
-        if not cfg.NETWORK.USE_GT:
-            req(model.root_net, not cfg.NETWORK.FREEZE_ROOTNET)
+        req(getattr(model, "pose_net", None), not cfg.NETWORK.TRAIN_ONLY_ROOTNET)
+        # proposals from ground truth: the root net is never called, so it must not ask for gradients either
+        req(getattr(model, "root_net", None), (not cfg.NETWORK.USE_GT) and (not cfg.NETWORK.FREEZE_ROOTNET))
     return [p for p in model.parameters() if p.requires_grad]
 
 
@@ -46,13 +43,12 @@ def main():
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "train")
     torch.manual_seed(D.rank_seed(int(cfg.get("SEED", 0)), rank))       # per-rank streams (sampling, augmentation)
-    if is_ssv(cfg) or cfg.get("WITH_SSV", False):
-        raise NotImplementedError(
-            f"{args.cfg}: MODEL {cfg.MODEL} / WITH_SSV - the self-supervised training loop (reference "
-            "lib/core/function.py:28-216, multi_person_posenet_ssv.py:197-501) is not built in this repo; only SSV "
-            "inference is (tools/validate_3d.py --with-ssv).  Refusing to train a different model under this config.")
+    ssv = is_ssv(cfg)
+    if bool(cfg.get("WITH_SSV", False)) != ssv:
+        raise ValueError(f"{args.cfg}: WITH_SSV = {cfg.get('WITH_SSV', False)} but MODEL = {cfg.MODEL}: the self-supervised "
+                         "loop and model go together (reference tools/train_3d.py:121,167-170)")
     train_loader = make_loader(cfg, args.frames, int(cfg.TRAIN.BATCH_SIZE), rank, world, seed=1,
-                               shuffle=bool(cfg.TRAIN.SHUFFLE))
+                               shuffle=bool(cfg.TRAIN.SHUFFLE), ssv=ssv)
     test_loader = make_loader(cfg, max(world, args.frames // 4), int(cfg.TEST.BATCH_SIZE), rank, world, seed=2,
                               shuffle=False)
     model = get_multi_person_pose_net(cfg, is_train=True).to(device)
@@ -67,10 +63,11 @@ def main():
     for epoch in range(start, int(cfg.TRAIN.END_EPOCH)):
         if hasattr(train_loader.sampler, "set_epoch"):
             train_loader.sampler.set_epoch(epoch)
-        stats = train_3d(cfg, ddp, optimizer, train_loader, epoch, out, None, device, args.max_iters)
+        loop = train_3d_ssv if ssv else train_3d                       # reference tools/train_3d.py:167-170
+        stats = loop(cfg, ddp, optimizer, train_loader, epoch, out, None, device, args.max_iters)
         sched.step()
-        prec = None if cfg.NETWORK.TRAIN_ONLY_2D else validate_3d(cfg, ddp, test_loader, epoch, out, device=device,
-                                                                  max_iters=args.max_iters)
+        prec = None if cfg.NETWORK.TRAIN_ONLY_2D else validate_3d(cfg, ddp, test_loader, epoch, out, with_ssv=ssv,
+                                                                  device=device, max_iters=args.max_iters)
         is_best = prec is not None and prec > best
         best = max(best, prec or 0.0)
         if rank == 0:
