@@ -63,6 +63,16 @@ def parse():
     ap.add_argument("--planar-input", action="store_true",
                     help="hand the heat-maps over as the reference does, planar (B,J,h,w): adds the re-tiling pass to the step")
     ap.add_argument("--no-check", action="store_true", help="skip the reference-golden check of the step's output")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave library-GEMM selection to the rocBLAS/hipBLASLt heuristics (default: opt in to TunableOp "
+                         "for the inference plan's GEMMs, V2VNet.tune_gemms(True); recorded in config.gemm_selection)")
+    ap.add_argument("--legs", default="auto",
+                    help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, or 'auto' "
+                         "(pose_stage + planar_handover always; train_step = BASELINE configs[2] when --gpus > 1) or 'none'")
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-find", choices=["search", "immediate"], default="search",
+                    help="MIOpen kernel selection for the train_step leg: search (cudnn.benchmark, one-off minutes) or immediate")
     return ap.parse_args()
 
 
@@ -79,8 +89,11 @@ def golden_inputs(cfg):
     return g, [torch.stack([0.35 * rnd[v][0], ppl[v][1]]) for v in range(V)]
 
 
-def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winograd=True, planar_input=False):
+def build_workload(batch, rank, dev, v2v_layout="cl3d", front_conv="fft", winograd=True, planar_input=False,
+                   tune_gemms=True):
     from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.v2v_net import V2VNet
+    V2VNet.tune_gemms(bool(tune_gemms))              # explicit opt-in: the library itself leaves TunableOp alone
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
     from selfpose3d_amd.project_layer import nhwc_heatmap_views
@@ -240,6 +253,26 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
                 out["traffic_source"] = rec.get("source")
         except Exception:
             pass
+    # the kernel as it runs INSIDE the step: behind ~1.5 ms of V2V that has pushed the (static) heat-maps out of the L2s
+    # and the Infinity Cache.  Emulated here by a 512 MiB fill between launches, the kernel alone between two events
+    # per iteration (the rocprofv3 in-graph average of the same kernel is in profiles/, see frac_in_step_source)
+    if cold:
+        thrash = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
+        run_k = k_brick_cl if step_cl else k_lin_planar
+        n_cc = max(20, iters // 6)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_cc)]
+        for _ in range(3):
+            thrash.fill_(1.0); run_k()
+        for e0, e1 in evs:
+            thrash.fill_(2.0)
+            e0.record(); run_k(); e1.record()
+        torch.cuda.synchronize(dev)
+        t_in = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
+        del thrash
+        out["kernel_us_in_step"] = round(t_in * 1e3, 2)
+        out["frac_in_step"] = round(alg_bytes / (t_in * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["frac_in_step_source"] = ("HIP events around the kernel alone, launched behind a 512 MiB fill (cold L2 / Infinity "
+                                      f"Cache), median of {n_cc}; rocprofv3 in-graph average: profiles/r03_bench_kernel_stats.md")
     if cold:
         nset = 8
         sets = [_lib.pack_heatmaps([torch.rand_like(x) for x in planar], jp=16) for _ in range(nset)]
@@ -298,6 +331,114 @@ def cpu_baseline_leg(cfg, meta, hms, model, reps):
             "value_1_thread": round(runs[1][0], 4), "host_cpus": host}
 
 
+def pose_stage_leg(dev, proposals_per_frame=4):
+    """BASELINE configs[2]/[4] inference side: PoseRegressionNet.forward_batched on B*K person proposals of the
+    bench rig - one indexed unprojection launch into 64^3 cubes, V2V in chunks of 8 cubes, fused soft-argmax"""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.pose_regression_net import PoseRegressionNet
+    from selfpose3d_amd.project_layer import nhwc_heatmap_views
+    B, K = 4, proposals_per_frame
+    cfg = load_config(None)
+    V, J = int(cfg.DATASET.CAMERA_NUM), int(cfg.NETWORK.NUM_JOINTS)
+    w, h = cfg.NETWORK.HEATMAP_SIZE
+    meta = syn.make_meta(B, V, cfg.NETWORK.IMAGE_SIZE)
+    hms = nhwc_heatmap_views(_lib.pack_heatmaps([x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=5)], jp=16), J)
+    net = PoseRegressionNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=73, scale=0.05)
+    net.eval().to(dev).use_channels_last(True)
+    g = torch.Generator().manual_seed(3)
+    gc = torch.zeros(B, K, 5)
+    gc[..., 0] = (torch.rand(B, K, generator=g) - 0.5) * 4000
+    gc[..., 1] = (torch.rand(B, K, generator=g) - 0.5) * 4000
+    gc[..., 2] = 800 + torch.rand(B, K, generator=g) * 400
+    gc = gc.to(dev)
+
+    def run():
+        with torch.no_grad():
+            return net.forward_batched(hms, meta, gc)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(dev)
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {"what": "PoseRegressionNet.forward_batched, 5 views 240x128 -> 64^3 cubes, eager launches",
+            "frames": B, "proposals": B * K, "ms_per_batch": round(ms, 3), "ms_per_person": round(ms / (B * K), 4),
+            "persons_per_s": round(B * K / ms * 1e3, 1)}
+
+
+def train_step_leg(args, rank, world, dev):
+    """BASELINE configs[2]: full train step (ResNet-50 backbone on 5 x 960x512 views, root net 80x80x20 + its loss, pose
+    net on 64^3 cubes, Adam), batch 2 per GPU, one process per GPU, DDP gradient all-reduce over RCCL when world > 1.
+    Frames are synthetic and built ONCE per rank, resident on the device (no loader inside the timed region); the root net
+    is randomly initialised, so the frame's ground-truth roots stand in for its proposals (proposal_override) and the
+    pose net runs once per person, as it does for a trained model."""
+    from torch.utils.data import default_collate
+    from selfpose3d_amd import distributed as D
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+    from selfpose3d_amd.synthetic_dataset import SyntheticPanoptic
+    cfg = load_config(os.path.join(ROOT, "configs", "panoptic_synthetic_960x512_cam5.yaml"))
+    Bt = int(cfg.TRAIN.BATCH_SIZE)
+    # MIOpen's immediate mode (benchmark off) picks kernels for the 3-D backward convolutions that are ~20x slower than the
+    # ones its search finds (2.2 s vs ~0.1 s per step, measured): the leg pays the one-off search in its warm-up steps
+    # (minutes on a box with an empty MIOpen user db; --train-find immediate skips it and says so in the record)
+    torch.backends.cudnn.benchmark = args.train_find == "search"
+    torch.manual_seed(D.rank_seed(0, rank))
+    model = get_multi_person_pose_net(cfg, is_train=True).to(dev)
+    model.use_channels_last(True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
+    find_unused = D.needs_find_unused(cfg)
+    ddp = D.wrap_ddp(model, dev, find_unused=find_unused)
+    ds = SyntheticPanoptic(cfg, num_frames=Bt, seed=D.rank_seed(1, rank) % 100000, max_people=3)
+    inputs, t2d, w2d, t3d, meta, _ = default_collate([ds[i] for i in range(Bt)])
+    inputs = [x.to(dev).contiguous(memory_format=torch.channels_last) for x in inputs]
+    t2d, w2d, t3d0 = [x.to(dev) for x in t2d], [x.to(dev) for x in w2d], t3d[0].to(dev)
+
+    def gt_proposals(grid_centers, m):
+        gc = torch.zeros_like(grid_centers)
+        gc[:, :, 3] = -1.0
+        roots, nper = m[0]["roots_3d"].float().to(gc.device), m[0]["num_person"]
+        for i in range(gc.shape[0]):
+            n = int(nper[i])
+            gc[i, :n, :3] = roots[i, :n]
+            gc[i, :n, 3] = torch.arange(n, device=gc.device, dtype=torch.float32)
+            gc[i, :n, 4] = 1.0
+        return gc
+    model.proposal_override = gt_proposals
+    ddp.train()
+    state = {}
+
+    def step():
+        _, _, _, l2d, l3d, lcord = ddp(views=inputs, meta=meta, targets_2d=t2d, weights_2d=w2d, targets_3d=t3d0)
+        loss = l2d.mean() + l3d.mean() + lcord.mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        state["loss"] = loss
+        return loss
+    el, _ = D.timed_steps(step, args.train_steps, args.train_warmup, dev)
+    V = len(inputs)
+    persons = int(sum(int(n) for n in meta[0]["num_person"]))
+    pose_calls = int(max(int(n) for n in meta[0]["num_person"]))         # one pose-net call per candidate slot in use
+    nbytes = int(sum(p.numel() for p in params) * 4)
+    return {"metric": "multi-view frames/sec, full train step (BASELINE configs[2])",
+            "value": round(D.job_throughput(Bt, args.train_steps, el, world), 3), "unit": "frames/s", "n_gpus": world,
+            "ms_per_step": round(1e3 * el / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
+            "batch_per_gpu": Bt, "views": V, "scaling": "weak", "dtype": "f32",
+            "collective": ("DDP gradient all-reduce over RCCL (backend nccl), bucket_cap 32 MB, overlapped with backward"
+                           if world > 1 else "none (single process)"),
+            "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
+            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
+            "loss_last": float(state["loss"]), "data": "synthetic frames built once per rank, resident on the device",
+            "config": "configs/panoptic_synthetic_960x512_cam5.yaml (ResNet-50, 80x80x20 root grid, 64^3 pose cubes)"}
+
+
 def cpu_reference_record():
     """the reference's own Python on CPU, timed in the build container by tools/time_reference_cpu.py (the reference
     cannot travel to the GPU box): static record, host described inside"""
@@ -331,7 +472,9 @@ def main():
 
     torch.backends.cudnn.benchmark = True
     cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
-                                                   not args.no_winograd, args.planar_input)
+                                                   not args.no_winograd, args.planar_input, not args.no_gemm_tuning)
+    legs = args.legs.split(",") if args.legs not in ("auto", "none") else \
+        ([] if args.legs == "none" else ["pose_stage", "planar_handover"] + (["train_step"] if world > 1 else []))
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
@@ -358,6 +501,39 @@ def main():
 
     # W untimed warm-up steps, then EXACTLY K steps between two barrier+synchronise points, slowest rank counts
     elapsed, out = D.timed_steps(step, args.steps, args.warmup, dev)
+
+    # ---- extra legs that every rank takes part in (same timing rule); rank 0 adds them to the one JSON line -----------
+    extra = {}
+    if "planar_handover" in legs and not args.planar_input:
+        # the reference hands the heat-maps over planar, (B,15,h,w) per view: the same step + the re-tiling pass
+        try:
+            planar = [x.contiguous() for x in hms]
+
+            def planar_step():
+                clear_pack_cache()
+                model.project_layer._cam_key = None
+                with torch.no_grad():
+                    return model(planar, meta)
+            pstep = planar_step
+            if mode == "hipgraph":
+                for _ in range(2):
+                    planar_step()
+                torch.cuda.synchronize(dev)
+                from selfpose3d_amd.graphs import GraphedRootNet
+                g_pl = GraphedRootNet(model, planar, meta)
+                pstep = (lambda: g_pl())
+            n_pl = max(10, min(50, args.steps))
+            el_pl, _ = D.timed_steps(pstep, n_pl, 5, dev)
+            extra["planar_handover"] = {"value": round(D.job_throughput(args.batch, n_pl, el_pl, world), 3), "unit": "samples/s",
+                                        "ms_per_step": round(1e3 * el_pl / n_pl, 4), "steps": n_pl,
+                                        "what": "same step with the reference's planar (B,15,h,w) hand-over: + pack_nhwc_kernel<16>"}
+        except Exception as e:
+            extra["planar_handover"] = {"error": f"{type(e).__name__}: {e}"}
+    if "train_step" in legs:
+        try:
+            extra["train_step"] = train_step_leg(args, rank, world, dev)
+        except Exception as e:                          # the headline must not die with a leg (all ranks fail alike)
+            extra["train_step"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         B = args.batch
@@ -386,6 +562,9 @@ def main():
                                           "inputs (tests/test_gpu_parity.py); measured 2.3e-6 (split Winograd) / 9.1e-6 (direct split) "
                                           "vs 2.4e-6 (fp32 MFMA) / 9.3e-6 (MIOpen direct fp32) on outputs of magnitude 8",
                        "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
+                       "gemm_selection": ("library heuristics" if args.no_gemm_tuning else
+                                          "PyTorch TunableOp for the plan's rocBLAS/hipBLASLt GEMMs, opted in by bench.py "
+                                          "(V2VNet.tune_gemms(True)); process-wide flags restored after every forward"),
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
@@ -425,6 +604,12 @@ def main():
         else:
             result["cpu_baseline"] = None
         result["cpu_reference"] = cpu_reference_record()
+        if "pose_stage" in legs:
+            try:
+                extra["pose_stage"] = pose_stage_leg(dev)
+            except Exception as e:
+                extra["pose_stage"] = {"error": f"{type(e).__name__}: {e}"}
+        result["legs"] = extra
         print(json.dumps(result), flush=True)
         if "output_check" in result and not result["output_check"]["ok"]:
             raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")

@@ -13,112 +13,172 @@
 namespace sp3d {
 
 constexpr int NMS_THREADS = 256;
-constexpr int NMS_PER_THREAD = 2;
-constexpr int NMS_CHUNK = NMS_THREADS * NMS_PER_THREAD;
+// tile of one workgroup: 4 x 8 x 32 voxels (z fastest, as in memory), 4 voxels per thread
+constexpr int NT_X = 4, NT_Y = 8, NT_Z = 32;
+constexpr int NMS_PER_THREAD = NT_X * NT_Y * NT_Z / NMS_THREADS;
 
 struct Cand {
     float v;
     int i;
 };
 
-// total order used for top-k: larger value first, then LOWER flat index (torch leaves ties
-// unspecified - SURVEY.md App. D-6; the oracle applies the same rule).
-__device__ __forceinline__ bool better(const Cand &a, const Cand &b)
+// Total order of the top-k: larger value first, then LOWER flat index (torch leaves ties unspecified - SURVEY.md
+// App. D-6; the oracle applies the same rule); -0 == +0 (a tie), NaN never wins.  As ONE unsigned 64-bit key whose
+// maximum is the best candidate: high word = the value's bits mapped to unsigned order (zeros merged), low word =
+// ~index; 0 = "no candidate".
+__device__ __forceinline__ unsigned long long cand_key(float v, int i)
 {
-    return (a.v > b.v) || (a.v == b.v && a.i < b.i);
+    if (v != v) return 0ull;
+    uint32_t b = __float_as_uint(v == 0.0f ? 0.0f : v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // -inf -> 0x007fffff ... +inf -> 0xff800000
+    return ((unsigned long long)b << 32) | (uint32_t)(~(uint32_t)i);
 }
+__device__ __forceinline__ int key_index(unsigned long long k) { return (int)(~(uint32_t)k); }
 
-__device__ __forceinline__ Cand wave_best(Cand c)
+// wave-wide maximum of a 64-bit key with DPP moves (no LDS round trips: the ds_bpermute form of this reduction was what
+// the selection rounds spent their time on); result in every lane
+template <int CTRL>
+__device__ __forceinline__ unsigned long long key_dpp(unsigned long long k)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Cand o;
-        o.v = __shfl_xor(c.v, off);
-        o.i = __shfl_xor(c.i, off);
-        if (better(o, c)) c = o;
-    }
-    return c;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
 }
-
-// block-wide arg-best; result valid in every thread.  sv/si: LDS scratch of NMS_THREADS/64 entries
-__device__ __forceinline__ Cand block_best(Cand c, float *sv, int *si)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
 {
-    c = wave_best(c);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
-    if (lane == 0) { sv[wave] = c.v; si[wave] = c.i; }
-    __syncthreads();
-    Cand r;
-    r.v = sv[0]; r.i = si[0];
+    unsigned long long o;
+    o = key_dpp<0xb1>(k); k = o > k ? o : k;      // quad_perm [1,0,3,2]
+    o = key_dpp<0x4e>(k); k = o > k ? o : k;      // quad_perm [2,3,0,1]
+    o = key_dpp<0x141>(k); k = o > k ? o : k;     // row_half_mirror
+    o = key_dpp<0x140>(k); k = o > k ? o : k;     // row_mirror: every lane of a 16-lane row holds the row maximum
+    // across the four rows: lanes 15, 31, 47, 63 on the scalar unit
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    unsigned long long r = 0ull;
 #pragma unroll
-    for (int w = 1; w < NMS_THREADS / 64; ++w) {
-        Cand o;
-        o.v = sv[w]; o.i = si[w];
-        if (better(o, r)) r = o;
+    for (int l = 15; l < 64; l += 16) {
+        const unsigned long long v = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)lo, l);
+        r = v > r ? v : r;
     }
     return r;
 }
 
-// nms value of voxel n: (x == max_pool3d(x,3,1,1)) * x     (core/proposal.py:28-32)
-__device__ __forceinline__ float nms_value(const float *__restrict__ c, int X, int Y, int Z, int n)
+// Top-k of the candidates a WAVE holds (NPT per lane) by k selection rounds that stay inside the wave: no barrier, no
+// LDS round trip (the workgroup-wide rounds this replaces cost two barriers each: 25 + 23 us for the two NMS kernels in
+// round 2).  Winner t: key -> okey[t] (0 = none left), value as computed -> oval[t].
+template <int NPT>
+__device__ __forceinline__ void wave_topk(unsigned long long (&mk)[NPT], const float (&mv)[NPT], int k,
+                                          unsigned long long *okey, float *oval)
 {
-    const int YZ = Y * Z;
-    const int x = n / YZ, r = n - x * YZ, y = r / Z, z = r - y * Z;
-    float m = -INFINITY;
-    for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = x + dx;
-        if (xx < 0 || xx >= X) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= Y) continue;
-            const float *row = c + ((size_t)xx * Y + yy) * Z;
-            for (int dz = -1; dz <= 1; ++dz) {
-                const int zz = z + dz;
-                if (zz < 0 || zz >= Z) continue;
-                const float v = row[zz];
-                m = (v > m || v != v) ? v : m;
-            }
-        }
+    const int lane = threadIdx.x & 63;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long best = mk[0];
+#pragma unroll
+        for (int e = 1; e < NPT; ++e) best = mk[e] > best ? mk[e] : best;
+        const unsigned long long win = wave_max_key(best);
+#pragma unroll
+        for (int e = 0; e < NPT; ++e)
+            if (win != 0ull && mk[e] == win) { oval[t] = mv[e]; mk[e] = 0ull; }      // keys are unique: one owner
+        if (lane == 0) okey[t] = win;
     }
-    const float self = c[n];
-    const float keep = (self == m) ? 1.0f : 0.0f;
-    return keep * self;
 }
 
-// stage 1: every workgroup owns NMS_CHUNK voxels of one sample and emits its local top-k
-__global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float *__restrict__ cubes, int X, int Y,
-                                                                    int Z, int k, Cand *__restrict__ ws)
+// second stage, ONE wave: the NW * k winners of the workgroup's waves (in LDS) -> the workgroup's top-k
+constexpr int NMS_WAVES = NMS_THREADS / 64;
+constexpr int TOPK2_PER_LANE = (NMS_WAVES * SP3D_MAX_TOPK + 63) / 64;
+
+// NaN-propagating maximum (the scan form of max_pool3d's window maximum, `m = (v > m || v != v) ? v : m`, is NaN as
+// soon as the window holds one): associative, so the 3x3x3 window separates into three 3-tap passes
+__device__ __forceinline__ float pmax(float a, float b)
 {
-    __shared__ float sv[NMS_THREADS / 64];
-    __shared__ int si[NMS_THREADS / 64];
+    return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b);
+}
+
+// stage 1: a workgroup owns a 4 x 8 x 32 tile of one sample.  The tile + a one-voxel halo (-inf outside the volume =
+// max_pool3d's padding) goes to LDS, the 27-tap window maximum is three separable passes there (6 LDS reads per voxel
+// instead of 27 scattered global loads with bounds tests), nms = (x == max) * x (core/proposal.py:28-32), then k
+// selection rounds emit the tile's top-k.
+__global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float *__restrict__ cubes, int X, int Y,
+                                                                    int Z, int k, int ntx, int nty, int ntz,
+                                                                    Cand *__restrict__ ws)
+{
+    constexpr int HX = NT_X + 2, HY = NT_Y + 2, HZ = NT_Z + 2;
+    __shared__ float sa[HX * HY * HZ];          // tile + halo
+    __shared__ float sb[HX * HY * NT_Z];        // after the z pass
+    __shared__ float sc[HX * NT_Y * NT_Z];      // after the y pass
+    __shared__ unsigned long long skey[NMS_WAVES * SP3D_MAX_TOPK], fkey[SP3D_MAX_TOPK];
+    __shared__ float sval[NMS_WAVES * SP3D_MAX_TOPK], fval[SP3D_MAX_TOPK];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    const int N = X * Y * Z;
-    const float *c = cubes + (size_t)b * N;
-    Cand mine[NMS_PER_THREAD];
+    const int tz = chunk % ntz, t1 = chunk / ntz, ty = t1 % nty, tx = t1 / nty;
+    const int x0 = tx * NT_X, y0 = ty * NT_Y, z0 = tz * NT_Z;
+    const float *c = cubes + (size_t)b * X * Y * Z;
+    const float ninf = -INFINITY;
+    for (int e = threadIdx.x; e < HX * HY * HZ; e += NMS_THREADS) {
+        const int hz = e % HZ, r = e / HZ, hy = r % HY, hx = r / HY;
+        const int x = x0 + hx - 1, y = y0 + hy - 1, z = z0 + hz - 1;
+        const bool in = (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
+        sa[e] = in ? c[((size_t)x * Y + y) * Z + z] : ninf;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HX * HY * NT_Z; e += NMS_THREADS) {
+        const int z = e % NT_Z, r = e / NT_Z;                       // r = hx * HY + hy
+        const float *p = sa + r * HZ + z;
+        sb[e] = pmax(pmax(p[0], p[1]), p[2]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < HX * NT_Y * NT_Z; e += NMS_THREADS) {
+        const int z = e % NT_Z, r = e / NT_Z, y = r % NT_Y, hx = r / NT_Y;
+        const float *p = sb + (hx * HY + y) * NT_Z + z;
+        sc[e] = pmax(pmax(p[0], p[NT_Z]), p[2 * NT_Z]);
+    }
+    __syncthreads();
+    float mv[NMS_PER_THREAD];
+    int mi[NMS_PER_THREAD];
+    unsigned long long mk[NMS_PER_THREAD];
 #pragma unroll
     for (int e = 0; e < NMS_PER_THREAD; ++e) {
-        const int n = chunk * NMS_CHUNK + e * NMS_THREADS + threadIdx.x;
-        mine[e].i = n < N ? n : 0x7fffffff;
-        mine[e].v = n < N ? nms_value(c, X, Y, Z, n) : -INFINITY;
+        const int t = e * NMS_THREADS + threadIdx.x;
+        const int z = t % NT_Z, r = t / NT_Z, y = r % NT_Y, x = r / NT_Y;
+        const int gx = x0 + x, gy = y0 + y, gz = z0 + z;
+        const bool in = gx < X && gy < Y && gz < Z;
+        const float *p = sc + (x * NT_Y + y) * NT_Z + z;
+        const float m = pmax(pmax(p[0], p[NT_Y * NT_Z]), p[2 * NT_Y * NT_Z]);
+        const float self = sa[((x + 1) * HY + (y + 1)) * HZ + z + 1];
+        const float keep = (self == m) ? 1.0f : 0.0f;
+        mv[e] = keep * self;
+        mi[e] = (gx * Y + gy) * Z + gz;
+        mk[e] = in ? cand_key(mv[e], mi[e]) : 0ull;
     }
+    // per-wave top-k, then wave 0 merges the four lists
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    wave_topk<NMS_PER_THREAD>(mk, mv, k, skey + wave * SP3D_MAX_TOPK, sval + wave * SP3D_MAX_TOPK);
+    __syncthreads();
+    if (wave != 0) return;
+    unsigned long long k2[TOPK2_PER_LANE];
+    float v2[TOPK2_PER_LANE];
+#pragma unroll
+    for (int e = 0; e < TOPK2_PER_LANE; ++e) {
+        const int j = e * 64 + lane, w = j / k, t = j - w * k;          // candidate t of wave w
+        const bool have = j < NMS_WAVES * k;
+        k2[e] = have ? skey[w * SP3D_MAX_TOPK + t] : 0ull;
+        v2[e] = have ? sval[w * SP3D_MAX_TOPK + t] : 0.0f;
+    }
+    wave_topk<TOPK2_PER_LANE>(k2, v2, k, fkey, fval);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     Cand *out = ws + ((size_t)b * nchunks + chunk) * k;
-    for (int t = 0; t < k; ++t) {
-        Cand best;
-        best.v = -INFINITY; best.i = 0x7fffffff;
-#pragma unroll
-        for (int e = 0; e < NMS_PER_THREAD; ++e)
-            if (better(mine[e], best)) best = mine[e];
-        const Cand win = block_best(best, sv, si);
-#pragma unroll
-        for (int e = 0; e < NMS_PER_THREAD; ++e)
-            if (mine[e].i == win.i) { mine[e].v = -INFINITY; mine[e].i = 0x7fffffff; }
-        if (threadIdx.x == 0) out[t] = win;
+    if (lane < k) {
+        Cand w;
+        const unsigned long long key = fkey[lane];
+        w.v = key != 0ull ? fval[lane] : -INFINITY;
+        w.i = key != 0ull ? key_index(key) : 0x7fffffff;
+        out[lane] = w;
     }
 }
 
-// stage 2: one workgroup per sample merges nchunks*k candidates, unravels and converts to mm.
-// Every thread keeps its strided share of the candidates in registers (<= MERGE_PER_THREAD), so the k
-// selection rounds touch no memory; larger candidate sets fall back to the in-memory loop.
+// stage 2: one workgroup per sample merges nchunks*k candidates (per-wave top-k over a strided share held in registers,
+// then wave 0 merges the four lists), and lanes 0..k-1 unravel their winner and convert it to mm in parallel.
+// Candidate sets beyond NMS_THREADS * MERGE_PER_THREAD are reduced in passes of that size (carry = the running top-k).
 constexpr int MERGE_PER_THREAD = 16;
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict__ ws, int ncand, int X, int Y, int Z,
@@ -127,62 +187,64 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict
                                                                int64_t *__restrict__ idx, float *__restrict__ locs,
                                                                float *__restrict__ gcent, float threshold)
 {
-    __shared__ float sv[NMS_THREADS / 64];
-    __shared__ int si[NMS_THREADS / 64];
+    __shared__ unsigned long long skey[NMS_WAVES * SP3D_MAX_TOPK], fkey[SP3D_MAX_TOPK];
+    __shared__ float sval[NMS_WAVES * SP3D_MAX_TOPK], fval[SP3D_MAX_TOPK];
     const int b = blockIdx.x;
-    Cand *cand = ws + (size_t)b * ncand;
+    const Cand *cand = ws + (size_t)b * ncand;
     const int YZ = Y * Z;
-    const bool inreg = ncand <= NMS_THREADS * MERGE_PER_THREAD;
-    Cand mine[MERGE_PER_THREAD];
-    if (inreg) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < SP3D_MAX_TOPK) { fkey[threadIdx.x] = 0ull; fval[threadIdx.x] = 0.0f; }
+    __syncthreads();
+    for (int base = 0; base < ncand; base += NMS_THREADS * MERGE_PER_THREAD) {
+        float mv[MERGE_PER_THREAD];
+        unsigned long long mk[MERGE_PER_THREAD];
 #pragma unroll
         for (int e = 0; e < MERGE_PER_THREAD; ++e) {
-            const int i = e * NMS_THREADS + threadIdx.x;
-            if (i < ncand) mine[e] = cand[i];
-            else { mine[e].v = -INFINITY; mine[e].i = 0x7fffffff; }
+            const int i = base + e * NMS_THREADS + threadIdx.x;
+            Cand cd; cd.v = -INFINITY; cd.i = 0x7fffffff;
+            if (i < ncand) cd = cand[i];
+            mv[e] = cd.v;
+            mk[e] = cd.i == 0x7fffffff ? 0ull : cand_key(cd.v, cd.i);
         }
-    }
-    for (int t = 0; t < k; ++t) {
-        Cand best;
-        best.v = -INFINITY; best.i = 0x7fffffff;
-        if (inreg) {
+        wave_topk<MERGE_PER_THREAD>(mk, mv, k, skey + wave * SP3D_MAX_TOPK, sval + wave * SP3D_MAX_TOPK);
+        __syncthreads();
+        if (wave == 0) {
+            // the four lists + the running top-k of the earlier passes
+            constexpr int NP = ((NMS_WAVES + 1) * SP3D_MAX_TOPK + 63) / 64;
+            unsigned long long k2[NP];
+            float v2[NP];
 #pragma unroll
-            for (int e = 0; e < MERGE_PER_THREAD; ++e)
-                if (better(mine[e], best)) best = mine[e];
-        } else {
-            for (int e = threadIdx.x; e < ncand; e += NMS_THREADS) {
-                const Cand c = cand[e];
-                if (better(c, best)) best = c;
+            for (int e = 0; e < NP; ++e) {
+                const int j = e * 64 + lane, w = j / k, t = j - w * k;
+                const bool have = j < (NMS_WAVES + 1) * k;
+                k2[e] = !have ? 0ull : (w < NMS_WAVES ? skey[w * SP3D_MAX_TOPK + t] : fkey[t]);
+                v2[e] = !have ? 0.0f : (w < NMS_WAVES ? sval[w * SP3D_MAX_TOPK + t] : fval[t]);
             }
+            __builtin_amdgcn_wave_barrier();
+            wave_topk<NP>(k2, v2, k, fkey, fval);
         }
-        const Cand win = block_best(best, sv, si);
-        if (inreg) {
-#pragma unroll
-            for (int e = 0; e < MERGE_PER_THREAD; ++e)
-                if (mine[e].i == win.i) { mine[e].v = -INFINITY; mine[e].i = 0x7fffffff; }
-        } else {
-            for (int e = threadIdx.x; e < ncand; e += NMS_THREADS)
-                if (cand[e].i == win.i) { cand[e].v = -INFINITY; cand[e].i = 0x7fffffff; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const int n = win.i == 0x7fffffff ? 0 : win.i;
-            const int ix = n / YZ, iy = (n % YZ) / Z, iz = n % Z;          // core/proposal.py:21-23
-            vals[(size_t)b * k + t] = win.i == 0x7fffffff ? 0.0f : win.v;
-            int64_t *ip = idx + ((size_t)b * k + t) * 3;
-            ip[0] = ix; ip[1] = iy; ip[2] = iz;
-            if (locs) {                                                      // cuboid_proposal_net.py:47-51
-                float *lp = locs + ((size_t)b * k + t) * 3;
-                lp[0] = ((float)ix / (float)(X - 1) * Lx + cx) - Lx / 2.0f;
-                lp[1] = ((float)iy / (float)(Y - 1) * Ly + cy) - Ly / 2.0f;
-                lp[2] = ((float)iz / (float)(Z - 1) * Lz + cz) - Lz / 2.0f;
-                if (gcent) {   // ProposalLayer.forward in eval (cuboid_proposal_net.py:62-81): [x,y,z, (score>thr)-1, score]
-                    float *gp = gcent + ((size_t)b * k + t) * 5;
-                    const float v = win.i == 0x7fffffff ? 0.0f : win.v;
-                    gp[0] = lp[0]; gp[1] = lp[1]; gp[2] = lp[2];
-                    gp[3] = (v > threshold ? 1.0f : 0.0f) - 1.0f;
-                    gp[4] = v;
-                }
+        __syncthreads();
+    }
+    if (threadIdx.x < k) {
+        const int t = threadIdx.x;
+        const unsigned long long win = fkey[t];
+        const bool have = win != 0ull;
+        const int n = have ? key_index(win) : 0;
+        const float v = have ? fval[t] : 0.0f;
+        const int ix = n / YZ, iy = (n % YZ) / Z, iz = n % Z;          // core/proposal.py:21-23
+        vals[(size_t)b * k + t] = v;
+        int64_t *ip = idx + ((size_t)b * k + t) * 3;
+        ip[0] = ix; ip[1] = iy; ip[2] = iz;
+        if (locs) {                                                      // cuboid_proposal_net.py:47-51
+            float *lp = locs + ((size_t)b * k + t) * 3;
+            lp[0] = ((float)ix / (float)(X - 1) * Lx + cx) - Lx / 2.0f;
+            lp[1] = ((float)iy / (float)(Y - 1) * Ly + cy) - Ly / 2.0f;
+            lp[2] = ((float)iz / (float)(Z - 1) * Lz + cz) - Lz / 2.0f;
+            if (gcent) {   // ProposalLayer.forward in eval (cuboid_proposal_net.py:62-81): [x,y,z, (score>thr)-1, score]
+                float *gp = gcent + ((size_t)b * k + t) * 5;
+                gp[0] = lp[0]; gp[1] = lp[1]; gp[2] = lp[2];
+                gp[3] = (v > threshold ? 1.0f : 0.0f) - 1.0f;
+                gp[4] = v;
             }
         }
     }
@@ -279,8 +341,7 @@ using namespace sp3d;
 extern "C" int64_t sp3d_nms_topk_workspace_bytes(int B, int X, int Y, int Z, int k)
 {
     if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || k <= 0) return 0;
-    const int64_t N = (int64_t)X * Y * Z;
-    const int64_t nchunks = (N + NMS_CHUNK - 1) / NMS_CHUNK;
+    const int64_t nchunks = (int64_t)((X + NT_X - 1) / NT_X) * ((Y + NT_Y - 1) / NT_Y) * ((Z + NT_Z - 1) / NT_Z);
     return (int64_t)B * nchunks * k * (int64_t)sizeof(Cand);
 }
 
@@ -294,10 +355,14 @@ extern "C" int sp3d_nms_proposals(const float *root_cubes, int B, int X, int Y, 
     if (grid_centers && !locs) return SP3D_ENULL;
     const int64_t N = (int64_t)X * Y * Z;
     if (N > 0x7ffffffe) return SP3D_ERANGE;
-    const int nchunks = (int)((N + NMS_CHUNK - 1) / NMS_CHUNK);
+    const int ntx = (X + NT_X - 1) / NT_X, nty = (Y + NT_Y - 1) / NT_Y, ntz = (Z + NT_Z - 1) / NT_Z;
+    const int64_t nch = (int64_t)ntx * nty * ntz;
+    if (nch > 0x7fffffff / (SP3D_MAX_TOPK + 1) || B > 65535) return SP3D_ERANGE;
+    const int nchunks = (int)nch;
     hipStream_t s = (hipStream_t)stream;
     Cand *ws = (Cand *)workspace;
-    hipLaunchKernelGGL(nms_chunk_topk_kernel, dim3(nchunks, B), dim3(NMS_THREADS), 0, s, root_cubes, X, Y, Z, k, ws);
+    hipLaunchKernelGGL(nms_chunk_topk_kernel, dim3(nchunks, B), dim3(NMS_THREADS), 0, s, root_cubes, X, Y, Z, k, ntx, nty,
+                       ntz, ws);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const float L[3] = {locs ? grid_size[0] : 0.f, locs ? grid_size[1] : 0.f, locs ? grid_size[2] : 0.f};

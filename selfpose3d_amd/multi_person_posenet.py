@@ -32,6 +32,11 @@ class MultiPersonPoseNet(nn.Module):
         self.root_id = cfg.DATASET.ROOTIDX
         self.mse = PerJointMSELoss()
         self.l1 = PerJointL1Loss()
+        # benchmark / test hook (None in normal use): callable(grid_centers, meta) -> grid_centers applied AFTER the root
+        # net ran.  A randomly initialised root net proposes nothing near the ground truth, so the pose net would be
+        # skipped; bench.py's train_step leg substitutes the frame's ground-truth roots to time a step with the number of
+        # pose-net passes a trained model has (root net, its loss and its backward still run).
+        self.proposal_override = None
 
     def use_channels_last(self, on: bool = True):
         if not self.train_only_2d:
@@ -77,6 +82,8 @@ class MultiPersonPoseNet(nn.Module):
             if targets_3d is not None:
                 loss_3d = self.mse(root_cubes, targets_3d.to(device))
             del root_cubes
+            if self.proposal_override is not None:
+                grid_centers = self.proposal_override(grid_centers, meta)
 
         pred = torch.zeros(B, self.num_cand, self.num_joints, 5, device=device)
         pred[:, :, :, 3:] = grid_centers[:, :, 3:].reshape(B, -1, 1, 2)          # :77-78

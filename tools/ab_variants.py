@@ -94,11 +94,17 @@ def main():
             for k, fn in fns.items():
                 times[k].append(timed(fn, args.iters if k != "planar" else max(5, args.iters // 10)))
         alg = 4.0 * B * (V * J * h * w + J * N)
-        report[name] = {"algorithmic_MB": round(alg / 1e6, 2)}
+        # 2 bytes per element for tensors stored as bf16
+        alg_by = {"nhwc_bf16_in": B * (2.0 * V * J * h * w + 4.0 * J * N), "nhwc_bf16_io": 2.0 * B * (V * J * h * w + J * N)}
+        report[name] = {"algorithmic_MB": round(alg / 1e6, 2),
+                        "algorithmic_MB_bf16_in": round(alg_by["nhwc_bf16_in"] / 1e6, 2),
+                        "algorithmic_MB_bf16_io": round(alg_by["nhwc_bf16_io"] / 1e6, 2)}
         for k, ts in times.items():
             med, mn = float(np.median(ts)), float(np.min(ts))
+            a = alg_by.get(k, alg)
             report[name][k] = {"median_us": round(med, 2), "min_us": round(mn, 2),
-                               "alg_GBps_at_median": round(alg / med / 1e3, 1) if not k.startswith("pack") else None}
+                               "alg_GBps_at_median": round(a / med / 1e3, 1) if not k.startswith("pack") else None,
+                               "frac_of_8TBps": round(a / med / 1e3 / 8000.0, 4) if not k.startswith("pack") else None}
     print(json.dumps(report, indent=1))
 
 
