@@ -42,6 +42,16 @@ struct Geom {
     int vec4;                     // 1: rows are 4-element aligned, 16-byte result pieces are allowed
     uint16_t *pass_mask;          // optional (P,N): bit j set iff 0 <= pre-clamp value of channel j <= 1 and the
                                   // voxel is not NaN-zeroed (where torch's clamp / index_put_ let gradient through)
+    // blockIdx -> (sample, tile) without run-time integer divisions (set_xcd_fields; round 3: the ~10 division sequences
+    // of the old prologue were ~250 of a brick wave's ~1 350 instructions, and these kernels are instruction-issue bound)
+    int xm_mode;                  // 0: B <= 8 and 8 % B == 0 (XCD groups per sample), 1: B % 8 == 0, 2: plain interleave
+    int xm_log2xps, xm_log2K;     // mode 0: XCDs per sample and tiles per chunk, both powers of two
+    int xm_rows;                  // mode 0: chunk rows per serving XCD (centre-out order)
+    int xm_tiles;                 // tiles (workgroups) per sample the fields were computed for
+    uint32_t xm_magic_tiles;      // floor(2^32 / tiles) + 1
+    // brick decode: wg -> (z chunk, y brick, x brick)
+    int bk_nxy, bk_nby;
+    uint32_t bk_magic_nxy, bk_magic_nby;
 };
 
 // torch.linspace(-L/2, L/2, n)[i] in fp32 (project_layer.py:28-30; ATen CPU kernel form)
@@ -358,7 +368,7 @@ __device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int K, int &b
         b = x / xps;
         const int sub = x - b * xps;
         int row = slot / K;                                   // chunk rows in dispatch order
-        if (order == 1) {                                     // centre-out: the cheap edge-of-volume tiles run last
+        if (order & 1) {                                      // centre-out: the cheap edge-of-volume tiles run last
             const int rows = ((tiles + K - 1) / K + xps - 1) / xps, mid = rows / 2;
             row = mid + ((row & 1) ? -((row + 1) >> 1) : (row >> 1));
         }
@@ -376,6 +386,55 @@ __device__ __forceinline__ bool xcd_map(int bid, int B, int tiles, int K, int &b
     b = lt / tiles;
     tile = lt - b * tiles;
     return b < B;
+}
+
+// host: fill the division-free map fields for `tiles` workgroups per sample and chunk size K = g.xcd_chunk
+inline void set_xcd_fields(Geom &g, int tiles)
+{
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    g.xm_tiles = tiles;
+    g.xm_magic_tiles = (uint32_t)((0x100000000ull / (uint64_t)(tiles > 0 ? tiles : 1)) + 1ull);
+    if (g.B <= 8 && (8 % g.B) == 0) {
+        const int xps = 8 / g.B, K = g.xcd_chunk;
+        g.xm_mode = 0; g.xm_log2xps = ilog2(xps); g.xm_log2K = ilog2(K);
+        g.xm_rows = ((tiles + K - 1) / K + xps - 1) / xps;
+    } else {
+        g.xm_mode = (g.B > 8 && (g.B % 8) == 0) ? 1 : 2;
+        g.xm_log2xps = g.xm_log2K = 0; g.xm_rows = 0;
+    }
+}
+inline void set_brick_fields(Geom &g, int nxy, int nby)
+{
+    g.bk_nxy = nxy; g.bk_nby = nby;
+    g.bk_magic_nxy = (uint32_t)((0x100000000ull / (uint64_t)(nxy > 0 ? nxy : 1)) + 1ull);
+    g.bk_magic_nby = (uint32_t)((0x100000000ull / (uint64_t)(nby > 0 ? nby : 1)) + 1ull);
+}
+
+// xcd_map() with the host-prepared fields: shifts and at most one magic division (same mapping, bit for bit)
+__device__ __forceinline__ bool xcd_map_fast(int bid, const Geom &g, int &b, int &tile)
+{
+    const int x = bid & 7, slot = bid >> 3;
+    if (g.xm_mode == 0) {
+        b = x >> g.xm_log2xps;
+        const int sub = x & ((1 << g.xm_log2xps) - 1);
+        int row = slot >> g.xm_log2K;
+        if (g.xcd_order & 1) {                                // centre-out: the cheap edge-of-volume tiles run last
+            const int mid = g.xm_rows / 2;
+            row = mid + ((row & 1) ? -((row + 1) >> 1) : (row >> 1));
+        }
+        const int chunk = (row << g.xm_log2xps) + sub;
+        tile = (chunk << g.xm_log2K) + (slot & ((1 << g.xm_log2K) - 1));
+        return tile < g.xm_tiles;
+    }
+    int q, r;
+    if (g.xm_mode == 1) {
+        udiv_magic((uint32_t)slot, (uint32_t)g.xm_tiles, g.xm_magic_tiles, q, r);
+        b = x + 8 * q; tile = r;
+        return b < g.B;
+    }
+    udiv_magic((uint32_t)(slot * 8 + x), (uint32_t)g.xm_tiles, g.xm_magic_tiles, q, r);
+    b = q; tile = r;
+    return b < g.B;
 }
 
 } // namespace sp3d

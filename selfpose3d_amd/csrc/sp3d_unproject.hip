@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
     __shared__ __attribute__((aligned(16))) float smem[NW * WLDS];
     int b, tile;
     if (XCD) {
-        if (!xcd_map(blockIdx.x, g.B, tiles_per_sample, g.xcd_chunk, b, tile, g.xcd_order)) return;
+        if (!xcd_map_fast(blockIdx.x, g, b, tile)) return;
     } else {
         b = blockIdx.x / tiles_per_sample;
         tile = blockIdx.x - b * tiles_per_sample;
@@ -682,9 +682,17 @@ __global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const
     constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
     extern __shared__ __attribute__((aligned(16))) float bsmem[];
     int b, wg;
-    if (!xcd_map(blockIdx.x, g.B, wgs_per_sample, g.xcd_chunk, b, wg, g.xcd_order)) return;
+    if (!xcd_map_fast(blockIdx.x, g, b, wg)) return;
     SP3D_DIAG_FLAGS();
-    const int zc = wg % nzc, t = wg / nzc, by = t % nby, bx = t / nby;
+    int zc, t;
+    if (!(g.xcd_order & 2)) {   // default (round 3): z slowest - consecutive workgroups sweep (y, x) inside one z-layer of bricks
+        // and an XCD's chunk is a z-slab: -3 % on all three grids (profiles/r03_ab_zslab.json)
+        udiv_magic((uint32_t)wg, (uint32_t)g.bk_nxy, g.bk_magic_nxy, zc, t);
+    } else {                    // bit 8 of the tuning `variant`: round 2's order, z fastest
+        zc = wg % nzc; t = wg / nzc;
+    }
+    int bx, by;
+    udiv_magic((uint32_t)t, (uint32_t)g.bk_nby, g.bk_magic_nby, bx, by);
     const int bs = g.sample_of ? g.sample_of[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = bx * BR, y0 = by * BR, zbase = zc * zw * BR, z0 = zbase + wave * BR;
@@ -1019,6 +1027,8 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.pass_mask = nullptr;
     g.xcd_chunk = 1;
     g.xcd_order = 0;
+    g.xm_mode = 2; g.xm_log2xps = g.xm_log2K = g.xm_rows = 0; g.xm_tiles = 1; g.xm_magic_tiles = 0;
+    g.bk_nxy = g.bk_nby = 1; g.bk_magic_nxy = g.bk_magic_nby = 0;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.sB = (long long)J * N; g.sJ = (int)N; g.sX = Y * Z; g.sY = Z; g.dense = 1; g.vec4 = 1;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
@@ -1095,6 +1105,8 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
             if ((variant >> 17) & 15) k = 1 << (((variant >> 17) & 15) - 1);
             gb.xcd_chunk = k;
         }
+        set_xcd_fields(gb, wgs);
+        set_brick_fields(gb, nbx * nby, nby);
         constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
         const size_t blds = (size_t)zw * WLDS * sizeof(float);
         dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
@@ -1124,10 +1136,12 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         const int ptiles = (g.N + 64 * nw - 1) / (64 * nw);
         const int ptotal = ptiles * g.B;
         dim3 pgrid(xcd ? xcd_grid_blocks(g.B, ptiles, g.xcd_chunk) : ptotal), pblock(64 * nw);
+        Geom gp = g;
+        set_xcd_fields(gp, ptiles);
 #define SP3D_PIPE(XCD_, NW_, CL_) \
-    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
+    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, NW_, CL_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, gp, ptiles, ptotal)
 #define SP3D_PIPE_T(XCD_, CL_, TI_, TO_) \
-    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, 1, CL_, TI_, TO_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, g, ptiles, ptotal)
+    hipLaunchKernelGGL((unproject_pipe_kernel<JP, XCD_, 1, CL_, TI_, TO_>), pgrid, pblock, 0, s, v, cam, centers, valid, cubes, grids, gp, ptiles, ptotal)
         if (io != 0) {   // bf16 storage variants: JP == 16, one wave per workgroup only
             if constexpr (JP == 16) {
                 if (nw != 1) return SP3D_EUNSUPPORTED;
@@ -1182,7 +1196,7 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     // chunk order: centre of the volume first (cheap edge tiles form the tail) when a sample is spread over >= 4 XCDs
     // (-2.5 % at B = 1); with 2 XCDs per sample it buys no time and costs L2 locality (HBM-side reads 75 -> 92 MB on
     // the bench workload), so the plain sweep stays there.  Tuning bit 21 forces the sweep.
-    g.xcd_order = (!((variant >> 21) & 1) && g.B <= 2) ? 1 : 0;
+    g.xcd_order = ((!((variant >> 21) & 1) && g.B <= 2) ? 1 : 0) | ((variant & 256) ? 2 : 0);
     if ((variant >> 17) & 15) {
         g.xcd_chunk = 1 << (((variant >> 17) & 15) - 1);   // tuning bits 17-20: log2(K)+1
     } else {

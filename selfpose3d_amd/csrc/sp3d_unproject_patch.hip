@@ -96,13 +96,15 @@ __global__ __launch_bounds__(64, 4) void unproject_wpatch_kernel(Views hm, const
     float4 *ws4 = reinterpret_cast<float4 *>(ws);
 
     int b, wg;
-    if (!xcd_map(blockIdx.x, g.B, wgs_per_sample, g.xcd_chunk, b, wg, g.xcd_order)) return;
+    if (!xcd_map_fast(blockIdx.x, g, b, wg)) return;
 #ifdef SP3D_PATCH_TL
     unsigned long long *tl = g_patch_tl ? g_patch_tl + (size_t)blockIdx.x * 32 : nullptr;
 #endif
     const int lane = threadIdx.x;
     PTL(0);
-    const int bz = wg % nbz, t = wg / nbz, by = t % nby, bx = t / nby;
+    int bz, t, bx, by;                                 // z slowest, as in the brick kernel
+    udiv_magic((uint32_t)wg, (uint32_t)g.bk_nxy, g.bk_magic_nxy, bz, t);
+    udiv_magic((uint32_t)t, (uint32_t)g.bk_nby, g.bk_magic_nby, bx, by);
     const int bs = __builtin_amdgcn_readfirstlane(g.sample_of ? g.sample_of[b] : b);
     const int x0 = bx * 4, y0 = by * 4, z0 = bz * 4;
     TO *cb = reinterpret_cast<TO *>(cubes) + (size_t)b * g.J * g.N;
@@ -334,6 +336,8 @@ int launch_patch(const Views &v, int Jp, const float *cam, const float *centers,
         while (k * 2 * xps * 2 <= wgs) k *= 2;
         gb.xcd_chunk = k;
     }
+    set_xcd_fields(gb, wgs);
+    set_brick_fields(gb, nbx * nby, nby);
     const size_t lds = WLDS_BYTES;
     dim3 grid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), block(64);
 #define SP3D_PATCH(TI_, TO_) \
