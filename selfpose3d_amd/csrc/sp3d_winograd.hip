@@ -904,7 +904,15 @@ __device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s
 __device__ __forceinline__ void split3(const float4 a, u32x4 &q0, u32x4 &q1)
 {
     const unsigned hi01 = pack_bf16(a.x, a.y), hi23 = pack_bf16(a.z, a.w);
-    const float r0 = a.x - bf16_lo(hi01), r1 = a.y - bf16_hi(hi01), r2 = a.z - bf16_lo(hi23), r3 = a.w - bf16_hi(hi23);
+    // a non-finite input has a non-finite hi piece and (inf - inf | NaN - NaN) = NaN as its residual: v_med3_f32(r, 0, r)
+    // is r for every number and 0 for NaN (one instruction per value), so mid = lo = 0 and the value travels in the hi
+    // piece alone.  The outputs that come out non-finite are then EXACTLY those of an fp32 convolution; their kind is
+    // the convolution's or NaN (inf * w is formed from the weight's three pieces, whose signs differ):
+    // tests/test_gpu_parity.py::test_direct_conv3_split_kernel_nonfinite_inputs.
+    const float r0 = __builtin_amdgcn_fmed3f(a.x - bf16_lo(hi01), 0.0f, a.x - bf16_lo(hi01));
+    const float r1 = __builtin_amdgcn_fmed3f(a.y - bf16_hi(hi01), 0.0f, a.y - bf16_hi(hi01));
+    const float r2 = __builtin_amdgcn_fmed3f(a.z - bf16_lo(hi23), 0.0f, a.z - bf16_lo(hi23));
+    const float r3 = __builtin_amdgcn_fmed3f(a.w - bf16_hi(hi23), 0.0f, a.w - bf16_hi(hi23));
     const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
     const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
     const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));

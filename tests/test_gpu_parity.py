@@ -1118,6 +1118,82 @@ def test_direct_conv3_split_kernel(shape):
     assert e <= 1.5 * e32 + 1e-6, (e, e32)
 
 
+def _nonfinite_case(C, dims, seed):
+    """activations with +inf, -inf, NaN and 1e30 planted at isolated voxels (at least 5 apart: no window holds two)"""
+    X, Y, Z = dims
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((1, C, X, Y, Z), generator=g) * 2.0
+    plants = [((2, 2, 2), 3, float("inf")), ((8, 3, 2), 0, float("-inf")), ((3, 9, 5), 5, float("nan")),
+              ((9, 9, 2), 7, 1e30), ((13, 3, 6), 1, -1e30)]
+    for (px, py, pz), c, v in plants:
+        if px < X and py < Y and pz < Z:
+            x[0, c % C, px, py, pz] = v
+    return x, [p for p in plants if p[0][0] < X and p[0][1] < Y and p[0][2] < Z]
+
+
+@pytest.mark.gpu
+def test_direct_conv3_split_kernel_nonfinite_inputs():
+    """round-2 review: the three-piece split must not turn +-inf into NaN (hi = inf, x - hi = NaN).  +inf / -inf / NaN / 1e30
+    activations through sp3d_conv3_split make EXACTLY the outputs non-finite that an fp32 convolution does (float64 referee:
+    no spreading, nothing lost); where the convolution gives +-inf the kernel gives that infinity or NaN (documented
+    below); finite values - also the 1e30-sized ones - stay accurate"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    C, O, dims = 32, 32, (16, 12, 8)
+    x, _ = _nonfinite_case(C, dims, 41)
+    g = torch.Generator(device="cpu").manual_seed(43)
+    w = torch.randn((O, C, 3, 3, 3), generator=g) * 0.05
+    shift = torch.zeros(O)
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last_3d)
+    y = _lib.conv3_split_(xg, _lib.conv_weights_split(w.cuda()), shift.cuda(), 0, None).cpu()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(y), fin)               # exactly the outputs an fp32 convolution makes non-finite
+    assert int((~fin).sum()) > 100
+    # ... of the same kind or NaN: an infinity reaches the matrix pipe in the operand's hi piece and meets the weight's
+    # three pieces, whose signs differ, so inf * w is formed as (inf * w_hi) + (inf * w_mid) + ... = NaN about half of the
+    # time; giving non-finite operands a path that meets w_hi only costs 3 more VALU per loaded value in the loader waves
+    # that already are this kernel's pole, and was not taken.  Never the other way round:
+    same_or_nan = (torch.isposinf(y) == torch.isposinf(ref)) & (torch.isneginf(y) == torch.isneginf(ref)) | torch.isnan(y)
+    assert bool(same_or_nan[~fin].all())
+    assert bool(torch.isnan(y)[torch.isnan(ref)].all())      # a NaN of the reference is never lost
+    big = ref.abs() > 1e20                                   # outputs that carry the 1e30 activations
+    assert float(((y.double() - ref)[fin & ~big]).abs().max()) <= 1e-5 * 10.0
+    assert float(((y.double() - ref)[fin & big] / ref[fin & big]).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["full", "half"])
+def test_winograd_split_kernels_confine_nonfinite_inputs(kind):
+    """Winograd F(2,3) transforms a 4x4x4 input patch per 2x2x2 output tile, so a non-finite input reaches every output of
+    the tiles whose patch holds it (any Winograd form does this, in fp32 too): outputs whose window holds the value are
+    non-finite as in the direct convolution, outputs of tiles whose patch is clean are finite and accurate"""
+    import torch.nn.functional as F
+    from selfpose3d_amd import _lib
+    C, O, dims = (32, 32, (16, 12, 8)) if kind == "full" else (64, 64, (16, 16, 6))
+    x, plants = _nonfinite_case(C, dims, 47)
+    g = torch.Generator(device="cpu").manual_seed(49)
+    w = torch.randn((O, C, 3, 3, 3), generator=g) * 0.05
+    ref = F.conv3d(torch.nan_to_num(x, nan=0.0, posinf=0.0, neginf=0.0).clamp(-1e3, 1e3).double(), w.double(), padding=1)
+    refnf = F.conv3d(x.double(), w.double(), padding=1)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last_3d)
+    U = _lib.wino_weights(w.cuda())
+    U3 = _lib.wino_weights_split(U) if kind == "full" else _lib.wino_weights_split(U, 16)
+    y = _lib.wino_fused_conv3d_(xg, U, torch.zeros(O).cuda(), 0, None, U3).cpu()
+    X, Y, Z = dims
+    dirty = torch.zeros((X, Y, Z), dtype=torch.bool)        # outputs of tiles whose 4x4x4 patch holds a planted value
+    for (px, py, pz), _, _ in plants:
+        for tx in range((X + 1) // 2):
+            for ty in range((Y + 1) // 2):
+                for tz in range((Z + 1) // 2):
+                    if 2 * tx - 1 <= px <= 2 * tx + 2 and 2 * ty - 1 <= py <= 2 * ty + 2 and 2 * tz - 1 <= pz <= 2 * tz + 2:
+                        dirty[2 * tx:2 * tx + 2, 2 * ty:2 * ty + 2, 2 * tz:2 * tz + 2] = True
+    clean = ~dirty
+    assert bool(torch.isfinite(y[0][:, clean]).all())
+    assert float((y[0][:, clean].double() - ref[0][:, clean]).abs().max()) <= 5e-5 * 10.0
+    assert bool((~torch.isfinite(y))[~torch.isfinite(refnf)].all())          # superset of the direct convolution's pattern
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims", [(2, (16, 12, 8)), (1, (9, 7, 5)), (1, (40, 24, 10))])
 def test_direct_conv3_split_activation_chain(dims):
