@@ -63,7 +63,9 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.sp3d_pack_heatmaps(views, dummy, 1, 2, 15, 15, 8, 8, None) == -4
     assert lib.sp3d_nms_topk(dummy, 1, 4, 4, 4, 33, None, None, dummy, dummy, None, dummy, None) == -1
     assert lib.sp3d_nms_topk(None, 1, 4, 4, 4, 10, None, None, dummy, dummy, None, dummy, None) == -2
-    assert lib.sp3d_nms_topk_workspace_bytes(4, 80, 80, 20, 10) == 4 * 250 * 10 * 8
+    # one k-entry candidate list per 4 x 8 x 32 voxel tile (round 3): 20 x 10 x 1 tiles per 80x80x20 sample
+    assert lib.sp3d_nms_topk_workspace_bytes(4, 80, 80, 20, 10) == 4 * 200 * 10 * 8
+    assert lib.sp3d_nms_topk_workspace_bytes(1, 64, 64, 64, 10) == 16 * 8 * 2 * 10 * 8
     assert lib.sp3d_soft_argmax(dummy, dummy, dummy, 0, 15, 64, C.c_float(100.0), None) == -1
     assert b"NULL" in lib.sp3d_error_string(-2)
 
