@@ -131,6 +131,9 @@ def g_train_step():
                 rec[f"{tag}_grad_root_out_f64"], rec[f"{tag}_grad_root_front_f64"] = ga64.numpy().copy(), gb64.numpy().copy()
             (a2.mean() + a3.mean() + ac.mean()).backward()
             rec[f"{tag}_grad_final_f64"] = fl64.grad.numpy().astype(np.float64)
+            gp64 = m64.pose_net.v2v_net.output_layer.weight.grad
+            if gp64 is not None:
+                rec[f"{tag}_grad_pose_out_f64"] = gp64.numpy().astype(np.float64)
             print("  float64 rerun: losses", float(a2), float(a3), float(ac))
         finally:
             torch.set_default_dtype(torch.float32)

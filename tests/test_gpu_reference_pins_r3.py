@@ -118,7 +118,9 @@ def test_supervised_train_step_vs_reference(dev, tag, deterministic):
     gp = model.pose_net.v2v_net.output_layer.weight.grad
     gp = np.zeros_like(g[f"{tag}_grad_pose_out"]) if gp is None else gp.cpu().numpy()
     if np.abs(g[f"{tag}_grad_pose_out"]).max() > 0:
-        assert _rel(gp, g[f"{tag}_grad_pose_out"]) <= 2e-3
+        # (a fixed 2e-3 against the reference's fp32 gradient held on most boxes and failed at 2.5e-3 on one: MIOpen's
+        # kernel choice moves it; the float64 yardstick is the honest bound here too)
+        close_to_truth(gp, f"{tag}_grad_pose_out")
     else:
         assert np.abs(gp).max() == 0.0                  # pose net not reached: zero-anchored, exactly zero gradient
 
