@@ -337,10 +337,16 @@ int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const floa
 int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode, int B,
                      int X, int Y, int Z, int C, int O, void *stream);
 
-/* The same with split ("S3") activations between consecutive layers: an S3 tensor is (B,X,Y,Z,C/4, 8 dwords), per voxel and
- * 4-channel group the two A operands [lo hi | hi mid] (bf16 pairs) of the three exact pieces of each fp32 value.
- * xs != NULL (C = 32): the input is read pre-split (x may be NULL); ys != NULL (modes 1, 2): the result is ALSO (y != NULL) or
- * ONLY (y == NULL) written as an S3 tensor for the next layer, whose loader waves then only copy.  16-byte aligned. */
+/* The same with split ("S3") activations between consecutive layers.  An S3 tensor of an (X,Y,Z) volume is ZERO-BORDERED and
+ * padded to whole blocks, 8-channel chunk slowest: (B, C/8, PX, PY, PZ, 2, 8 dwords) with (PX,PY,PZ) = sp3d_conv3_s3_dims(X,Y,Z)
+ * = (16 ceil(X/16) + 2, 8 ceil(Y/8) + 2, 4 ceil(Z/4) + 2); volume voxel (x,y,z) lives at (x+1, y+1, z+1), and per voxel and
+ * 4-channel group (channel = 8 chunk + 4 group + q) it holds the two A operands [lo hi | hi mid] (bf16 pairs) of the three
+ * exact pieces of each fp32 value.  The CALLER zeroes the
+ * tensor once; the kernels only ever write volume voxels, so the border stays zero across calls.
+ * xs != NULL (C = 32): the input is read pre-split (x may be NULL) - the loader waves then move it with
+ * global_load_lds_dwordx4, no bounds tests, no VALU; ys != NULL (modes 1, 2): the result is ALSO (y != NULL) or ONLY
+ * (y == NULL) written as an S3 tensor for the next layer.  16-byte aligned. */
+int sp3d_conv3_s3_dims(int X, int Y, int Z, int *padded3);
 int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
                         const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream);
 

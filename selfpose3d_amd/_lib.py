@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_conv3_s3_dims", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -605,29 +605,56 @@ def conv_weights_split(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo, hi, hi, mid, mid], -2).contiguous()        # the B operands {bh,bl} {bh,bh} {bm,bm}
 
 
+def conv3_s3_dims(X: int, Y: int, Z: int):
+    """padded extents (PX, PY, PZ) of the zero-bordered split tensor of an (X,Y,Z) volume (include/sp3d.h)"""
+    lib = load()
+    out = (C.c_int * 3)()
+    check(lib.sp3d_conv3_s3_dims(int(X), int(Y), int(Z), out), "sp3d_conv3_s3_dims")
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def conv3_s3_empty(B: int, X: int, Y: int, Z: int, channels: int, device) -> torch.Tensor:
+    """a zeroed S3 tensor (B,channels/8,PX,PY,PZ,2,8) int32 for an (X,Y,Z) volume; the kernels keep its border zero, so it
+    can be handed to conv3_split_(out_s3=...) again and again"""
+    PX, PY, PZ = conv3_s3_dims(X, Y, Z)
+    return torch.zeros((B, channels // 8, PX, PY, PZ, 2, 8), dtype=torch.int32, device=device)
+
+
 def conv3_split_(x: Optional[torch.Tensor], W3: torch.Tensor, shift: torch.Tensor, mode: int,
                  residual: Optional[torch.Tensor] = None, x_s3: Optional[torch.Tensor] = None, want_f32: bool = True,
-                 want_s3: bool = False):
+                 want_s3: bool = False, dims=None, out_s3: Optional[torch.Tensor] = None):
     """3x3x3 stride-1 'same' conv of channels_last_3d x with the fused epilogue, direct (implicit GEMM) on the bf16 matrix
-    pipe with exact three-piece splits; W3 = conv_weights_split(w).  x_s3: the input as an S3 tensor (B,X,Y,Z,C/4,8) int32
-    written by the previous layer (x may then be None); want_s3: also return the result as an S3 tensor.
-    Returns y, or (y | None, y_s3) when want_s3."""
+    pipe with exact three-piece splits; W3 = conv_weights_split(w).  x_s3: the input as a zero-bordered S3 tensor
+    (B,C/8,PX,PY,PZ,2,8) int32 written by the previous layer (x may then be None; dims = (X,Y,Z) of the volume, taken from
+    x / residual when given); want_s3: also return the result as an S3 tensor (out_s3: write it there - a tensor from
+    conv3_s3_empty - instead of a new zeroed one).  Returns y, or (y | None, y_s3) when want_s3."""
     lib = load()
     src = x if x is not None else x_s3
     _require_cuda(src, "x")
-    if x_s3 is not None:
-        B, X, Y, Z, G, _ = (int(v) for v in x_s3.shape)
-        Cc = 4 * G
-        if x_s3.dtype != torch.int32 or not x_s3.is_contiguous():
-            raise Sp3dError("conv3_split_: x_s3 must be a dense int32 (B,X,Y,Z,C/4,8) tensor")
-    else:
+    if x is not None:
         B, Cc, X, Y, Z = (int(v) for v in x.shape)
-        if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        if x_s3 is None and (not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32):
             raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
+    elif residual is not None:
+        B, _, X, Y, Z = (int(v) for v in residual.shape)
+    elif dims is not None:
+        B = int(x_s3.shape[0])
+        X, Y, Z = (int(v) for v in dims)
+    else:
+        raise Sp3dError("conv3_split_: dims=(X,Y,Z) needed with a split input and no x / residual")
+    if x_s3 is not None:
+        Cc = 8 * int(x_s3.shape[1])
+        if x_s3.dtype != torch.int32 or not x_s3.is_contiguous() or \
+                tuple(x_s3.shape) != (B, Cc // 8) + conv3_s3_dims(X, Y, Z) + (2, 8):
+            raise Sp3dError("conv3_split_: x_s3 must be a dense int32 (B,C/8,PX,PY,PZ,2,8) tensor (conv3_s3_dims)")
     O = int(W3.shape[3])
     dev = src.device
     y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3) if want_f32 else None
-    ys = torch.empty((B, X, Y, Z, O // 4, 8), dtype=torch.int32, device=dev) if want_s3 else None
+    ys = None
+    if want_s3:
+        ys = out_s3 if out_s3 is not None else conv3_s3_empty(B, X, Y, Z, O, dev)
+        if ys.dtype != torch.int32 or not ys.is_contiguous() or tuple(ys.shape) != (B, O // 8) + conv3_s3_dims(X, Y, Z) + (2, 8):
+            raise Sp3dError("conv3_split_: out_s3 must be a dense int32 (B,O/8,PX,PY,PZ,2,8) tensor (conv3_s3_empty)")
     if residual is not None and (tuple(residual.shape) != (B, O, X, Y, Z) or
                                  not residual.is_contiguous(memory_format=torch.channels_last_3d)):
         residual = residual.contiguous(memory_format=torch.channels_last_3d)

@@ -889,6 +889,36 @@ constexpr int CD_BUF = 2 * CD_PLANE;                                   // 17 328
 constexpr int CD_NV4 = CD_RX * CD_RY * CD_RZ * 2;                      // float4 per item: 2 160
 constexpr int CD_PROD = 4;                                             // producer waves: one per SIMD
 constexpr int CD_PER = (CD_NV4 + 64 * CD_PROD - 1) / (64 * CD_PROD);   // 9 float4 per producer lane
+// split ("S3") input: the staged buffer is a linear array of 16-byte slots (2 per voxel and 4-channel group, + 1 of padding
+// per z plane); one global_load_lds_dwordx4 fills 64 consecutive slots, 68 of them fill a buffer (the last one runs 20 slots
+// past CD_BUF, hence the buffer stride below)
+constexpr int CD_NSLOT = CD_BUF / 4;                                   // 4 332
+constexpr int CD_NDMA = (CD_NSLOT + 63) / 64;                          // 68
+constexpr int CD_DMA_PER = CD_NDMA / CD_PROD;                          // 17 per loader wave
+static_assert(CD_NDMA % CD_PROD == 0, "DMA instructions must divide over the loader waves");
+constexpr int CD_BUFS = CD_NDMA * 256;                                 // buffer stride in dwords: 17 408 = 69 632 B
+// zero-bordered S3 tensor of an (X,Y,Z) volume: (B, C/8, PX, PY, PZ, 2, 8 dwords), whole blocks + 1 voxel of zeros all round
+__host__ __device__ constexpr int cd_pad(int n, int blk) { return (n + blk - 1) / blk * blk + 2; }
+
+// Pause (x 64 cycles) after every DMA instruction of a loader wave: 17 back-to-back DMA instructions sit in the CU's
+// texture-address queue in front of the consumers' weight loads (prefetched one step = ~1 100 cycles ahead), and the matrix
+// stream then waits for its weights - tap loop 14.0 k cycles per item unthrottled, 12.5 k with 4, 12.3 k with 8 (but then
+// the DMA (13 k) is longer than the item); tools/conv3_timeline.py --s3 --var=sl2|sl4|sl8.
+#ifndef SP3D_CD_DMA_SLEEP
+#define SP3D_CD_DMA_SLEEP 4
+#endif
+#ifndef SP3D_CD_DMA_POLICY
+#define SP3D_CD_DMA_POLICY ""
+#endif
+// 16 bytes per lane from gbase + voff straight into LDS at lds_dst + 16 * lane (no VGPR round trip, no ds_write)
+__device__ __forceinline__ void cd_lds_dma16(uint32_t voff, uint32_t lds_dst, const char *gbase)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" SP3D_CD_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(gbase)
+                 : "memory");
+}
 
 struct CdRec { u32x4 hl, hh, mm; };                                    // weight record: B operands {bh,bl} {bh,bh} {bm,bm}
 
@@ -933,7 +963,12 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
                         int NBY, int NBZ, int nblocks, const unsigned *__restrict__ xs, unsigned *__restrict__ ys)
 {
     constexpr int O = 32, NCH = C / 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUF dwords + 4 x 1024 floats of scratch
+    // operand roles: a split result wants (voxel, 4 consecutive channels) per lane = weights as the A operand (rows), an
+    // fp32-only result wants (channel, 16 voxels) per lane = full 128-byte rows per store instruction (the transposed form's
+    // 32-byte pieces cost 8-10 k cycles per block against 3-6 k)
+    constexpr bool SWAP = (OUT & 2) != 0;
+    const int PX = NBX * CD_BX + 2, PY = NBY * CD_BY + 2, PZ = NBZ * CD_BZ + 2;       // S3 tensors: zero-bordered, whole blocks
+    extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUFS dwords + 4 x 1024 floats of scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
     const int my_blocks = ((int)blockIdx.x < nblocks) ? (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int n_items = my_blocks * NCH;
@@ -949,14 +984,62 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     if (wave >= 4) {
         // ---------------- producers: item k -> buffer k & 1 ----------------
         const int pt = tid - 256;                                          // 0 .. 64*CD_PROD-1
-        // VALU issue on a SIMD goes to the older wave first: without priority the (younger) producers got the slots the
-        // consumer's matrix stream left over - 28 cycles per instruction, 14 k cycles per item against the consumers' 12 k
-        if (!IN_S3) __builtin_amdgcn_s_setprio(2);        // (copy-only loaders fit into the leftover slots: raising them costs
-                                                          // the consumers more than it gains, 15 k vs 11.6 k cycles per item)
+        if (IN_S3) {
+            // split input (written by the previous layer's epilogue into a zero-bordered tensor): no bounds, no VALU, no
+            // ds_write - 17 global_load_lds_dwordx4 per wave and item.  Slot s of the buffer is (4-channel group, vz, vy, vx,
+            // half record); its offset from the region's first voxel does not depend on the item.  (With VGPR copies the
+            // loaders' ~50 instructions and bounds tests per item cost the consumers 2.3 k of their 11.7 k cycles: a
+            // co-resident wave's instruction delays the matrix stream by ~20 cycles, tools/conv3_timeline.py.)
+            const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;
+            uint32_t voff[CD_DMA_PER];
+#pragma unroll
+            for (int u = 0; u < CD_DMA_PER; ++u) {
+                const int sl = (pw * CD_DMA_PER + u) * 64 + lane;
+                const int plane = sl / (CD_PLANE / 4), r = sl % (CD_PLANE / 4);
+                const int vz = r / (CD_ZP / 4), r2 = r % (CD_ZP / 4);
+                const int vy = r2 / (CD_RX * 2), r3 = r2 % (CD_RX * 2);
+                const bool real = sl < CD_NSLOT && r2 < CD_RY * CD_RX * 2;            // else: padding slot, reads offset 0
+                voff[u] = real ? (uint32_t)((((r3 >> 1) * PY + vy) * PZ + vz) * 64 + plane * 32 + (r3 & 1) * 16) : 0u;
+            }
+            const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)cd_lds) + (uint32_t)pw * CD_DMA_PER * 1024u;
+            for (int k = 0; k <= n_items; ++k) {
+                if (k < n_items) {
+                    { const int item = k; CD_STAMP(0); }
+                    int b, ox0, oy0, oz0;
+                    decode(k, b, ox0, oy0, oz0);
+                    // region voxel (0,0,0) = volume voxel (ox0-1, ..) = padded voxel (ox0, oy0, oz0)
+                    // (chunk-major tensor: the 64 bytes of a voxel's 8-channel chunk, then z - a region row is 384 contiguous bytes)
+#ifdef SP3D_CD_DMA_SAME
+                    ox0 = 16; oy0 = 8; oz0 = 4; b = 0;                     // measurement build: every item reads one hot region
+#endif
+                    const int64_t pv0 = ((((int64_t)b * NCH + k % NCH) * PX + ox0) * PY + oy0) * PZ + oz0;
+                    const char *gb = reinterpret_cast<const char *>(xs) + pv0 * 64;
+                    const uint64_t gu = (uint64_t)(size_t)gb;
+                    const uint32_t glo = __builtin_amdgcn_readfirstlane((uint32_t)gu), ghi = __builtin_amdgcn_readfirstlane((uint32_t)(gu >> 32));
+                    const char *gbs = reinterpret_cast<const char *>((size_t)(((uint64_t)ghi << 32) | glo));
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(k & 1) * (CD_BUFS * 4u));
+#pragma unroll
+                    for (int u = 0; u < CD_DMA_PER; ++u) {
+                        cd_lds_dma16(voff[u], dst + (uint32_t)u * 1024u, gbs);
+#if SP3D_CD_DMA_SLEEP
+                        __builtin_amdgcn_s_sleep(SP3D_CD_DMA_SLEEP);
+#endif
+                    }
+                    { const int item = k; CD_STAMP(1); }
+                    __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0): the DMA data is in LDS
+                    { const int item = k; CD_STAMP(2); }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+        // fp32 input.  VALU issue on a SIMD goes to the older wave first: without priority the (younger) producers got the
+        // slots the consumer's matrix stream left over - 28 cycles per instruction, 14 k cycles per item against the
+        // consumers' 12 k
+        __builtin_amdgcn_s_setprio(2);
         // the producers get one issue slot per consumer matrix instruction (324 per item): everything that does not depend
         // on the item is computed once - LDS offset, offset inside the sample, region coordinates
         float4 d[CD_PER];
-        u32x4 e0[IN_S3 ? CD_PER : 1], e1[IN_S3 ? CD_PER : 1];
         int lo_[CD_PER], rel[CD_PER], vxyz[CD_PER];
 #pragma unroll
         for (int u = 0; u < CD_PER; ++u) {
@@ -964,8 +1047,7 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
             const int v = idx >> 1, half = idx & 1;
             const int vx = v % CD_RX, vy = (v / CD_RX) % CD_RY, vz = v / (CD_RX * CD_RY);
             lo_[u] = idx < CD_NV4 ? half * CD_PLANE + vz * CD_ZP + vy * CD_ROW + vx * CD_VOX : -1;
-            // fp32 input: C floats per voxel; S3 input: C/4 records of 8 dwords = 2 C dwords per voxel
-            rel[u] = IN_S3 ? ((vx * Y + vy) * Z + vz) * 2 * C + half * 8 : ((vx * Y + vy) * Z + vz) * C + half * 4;
+            rel[u] = ((vx * Y + vy) * Z + vz) * C + half * 4;
             vxyz[u] = idx < CD_NV4 ? (vx | (vy << 8) | (vz << 16)) : 0x00ffffff;      // 255: never in range
         }
         auto issue = [&](int k) {                                          // loads of item k: in flight until iteration k
@@ -974,51 +1056,33 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
             // element offset of region voxel (0,0,0), chunk k % NCH; may be negative at the volume border (never read there)
             const int64_t vox0 = (((int64_t)b * X + (ox0 - 1)) * Y + (oy0 - 1)) * Z + (oz0 - 1);
             const float *xb = x + vox0 * C + (k % NCH) * 8;
-            const unsigned *sb = xs + vox0 * 2 * C + (k % NCH) * 16;
             // voxel (vx,vy,vz) is inside the volume iff vx in [xlo, xhi) ...: wave-uniform bounds
             const int xlo = 1 - ox0, xhi = X + 1 - ox0, ylo = 1 - oy0, yhi = Y + 1 - oy0, zlo = 1 - oz0, zhi = Z + 1 - oz0;
 #pragma unroll
             for (int u = 0; u < CD_PER; ++u) {
                 const int vx = vxyz[u] & 255, vy = (vxyz[u] >> 8) & 255, vz = vxyz[u] >> 16;
                 const bool in = vx >= xlo && vx < xhi && vy >= ylo && vy < yhi && vz >= zlo && vz < zhi;
-                if (IN_S3) {
-                    e0[u] = u32x4{0u, 0u, 0u, 0u};
-                    e1[u] = u32x4{0u, 0u, 0u, 0u};
-                    if (in) {
-                        e0[u] = *reinterpret_cast<const u32x4 *>(sb + rel[u]);
-                        e1[u] = *reinterpret_cast<const u32x4 *>(sb + rel[u] + 4);
-                    }
-                } else {
-                    d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (in) d[u] = *reinterpret_cast<const float4 *>(xb + rel[u]);
-                }
+                d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in) d[u] = *reinterpret_cast<const float4 *>(xb + rel[u]);
             }
         };
         if (n_items > 0) issue(0);
         for (int k = 0; k <= n_items; ++k) {
             if (k < n_items) {
                 { const int item = k; CD_STAMP(0); }
-                unsigned *buf = cd_lds + (k & 1) * CD_BUF;
+                unsigned *buf = cd_lds + (k & 1) * CD_BUFS;
 #ifdef SP3D_CD_TIMELINE
                 __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) lgkmcnt(0): separates the load wait from the split
                 { const int item = k; CD_STAMP(3); }      // (slot 3 is overwritten after the barrier for consumers only)
 #endif
 #pragma unroll
                 for (int u = 0; u < CD_PER; ++u) {
-                    if (IN_S3) {
-                        if (lo_[u] >= 0) {
-                            unsigned *p = buf + lo_[u];
-                            *reinterpret_cast<u32x4 *>(p) = e0[u];
-                            *reinterpret_cast<u32x4 *>(p + 4) = e1[u];
-                        }
-                    } else {
-                        u32x4 q0, q1;
-                        split3(d[u], q0, q1);
-                        if (lo_[u] >= 0) {
-                            unsigned *p = buf + lo_[u];
-                            *reinterpret_cast<u32x4 *>(p) = q0;
-                            *reinterpret_cast<u32x4 *>(p + 4) = q1;
-                        }
+                    u32x4 q0, q1;
+                    split3(d[u], q0, q1);
+                    if (lo_[u] >= 0) {
+                        unsigned *p = buf + lo_[u];
+                        *reinterpret_cast<u32x4 *>(p) = q0;
+                        *reinterpret_cast<u32x4 *>(p + 4) = q1;
                     }
                 }
                 { const int item = k; CD_STAMP(1); }
@@ -1056,7 +1120,7 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     __syncthreads();                                   // item 0 staged
     for (int k = 1; k <= n_items; ++k) {
         const int item = k - 1, cc = item % NCH;
-        const unsigned *ab = cd_lds + (item & 1) * CD_BUF + a_off;
+        const unsigned *ab = cd_lds + (item & 1) * CD_BUFS + a_off;
         if (cc == 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -1084,11 +1148,11 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.lh[i + dx], w0.d[dx].hl, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].hl, a0.lh[i + dx], acc[i]) : mfma_bf16(a0.lh[i + dx], w0.d[dx].hl, acc[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].hh, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].hh, a0.hm[i + dx], acc[i]) : mfma_bf16(a0.hm[i + dx], w0.d[dx].hh, acc[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].mm, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].mm, a0.hm[i + dx], acc[i]) : mfma_bf16(a0.hm[i + dx], w0.d[dx].mm, acc[i]);
             }
             // issue order: one load between matrix instructions (a wave blocked on LDS issue cannot issue its matrix
             // instructions either: tools/conv3_timeline.py)
@@ -1108,7 +1172,7 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
             w0 = w1;
         }
         CD_STAMP(1);
-        if (cc == NCH - 1) {
+        if (!SWAP && cc == NCH - 1) {
             // D of the 32x32 MFMA: lane (col = t, h) holds rows m = 8 (v >> 2) + (v & 3) + 4 h, v = 0..15, of every accumulator;
             // row m of accumulator i is voxel (x = 4 wave + i, y = m & 7, z = m >> 3).  Each accumulator goes through the wave's
             // 4 KB of LDS scratch [voxel][channel] and comes back as (voxel, 4 channels) per lane: shift, residual, ReLU,
@@ -1136,7 +1200,7 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
                         y[idx] = val;
                     }
             } else {
-            float *scr = reinterpret_cast<float *>(cd_lds + 2 * CD_BUF) + wave * 1024;
+            float *scr = reinterpret_cast<float *>(cd_lds + 2 * CD_BUFS) + wave * 1024;
             const int g = lane & 7;                                          // channel group of this lane on the way out
             const float4 sh4 = *reinterpret_cast<const float4 *>(shift + 4 * g);
 #pragma unroll
@@ -1163,19 +1227,57 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #endif
                         {
                             if (OUT & 1) *reinterpret_cast<float4 *>(y + vox * O + 4 * g) = a;
-                            if (OUT & 2) {
-                                u32x4 q0, q1;
-                                split3(a, q0, q1);
-                                unsigned *p = ys + (vox * (O / 4) + g) * 8;
-                                *reinterpret_cast<u32x4 *>(p) = q0;
-                                *reinterpret_cast<u32x4 *>(p + 4) = q1;
-                            }
                         }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            }
+        }
+        if (SWAP && cc == NCH - 1) {
+            // The weights are the A operand (rows = output channels) and the voxels the B operand (columns): lane (t, h)
+            // holds, of voxel (x = 4 wave + i, y = t & 7, z = t >> 3), the channels 8 k + 4 h + j in acc[i][4 k + j] - four
+            // consecutive channels per k, which is a float4 of the channels-last result and one record of the split
+            // result, straight from the accumulators (the transposed roles needed a trip through LDS: 6-9 k cycles a block)
+            int b, ox0, oy0, oz0;
+            decode(item, b, ox0, oy0, oz0);
+            const int yo = oy0 + (t & 7), zo = oz0 + (t >> 3);
+            float4 sh4[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) sh4[k4] = *reinterpret_cast<const float4 *>(shift + 8 * k4 + 4 * h);
+            const bool inyz = yo < Y && zo < Z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xo = ox0 + 4 * wave + i;
+                if (inyz && xo < X) {
+                    const int64_t vox = (((int64_t)b * X + xo) * Y + yo) * Z + zo;
+                    const int64_t pvox = (((int64_t)b * (O / 8) * PX + xo + 1) * PY + yo + 1) * PZ + zo + 1;      // chunk 0
+                    const int64_t pchunk = (int64_t)PX * PY * PZ;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        float4 a = make_float4(acc[i][4 * k4] + sh4[k4].x, acc[i][4 * k4 + 1] + sh4[k4].y,
+                                               acc[i][4 * k4 + 2] + sh4[k4].z, acc[i][4 * k4 + 3] + sh4[k4].w);
+                        float4 rr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (MODE >= 2) rr = *reinterpret_cast<const float4 *>(res + vox * O + 8 * k4 + 4 * h);
+                        if (MODE == 2) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
+                        if (MODE >= 1) { a.x = fmaxf(a.x, 0.0f); a.y = fmaxf(a.y, 0.0f); a.z = fmaxf(a.z, 0.0f); a.w = fmaxf(a.w, 0.0f); }
+                        if (MODE == 3) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
+#if SP3D_W16_ABLATE & 16
+                        if (a.x == 123.456f)
+#endif
+                        {
+                            if (OUT & 1) *reinterpret_cast<float4 *>(y + vox * O + 8 * k4 + 4 * h) = a;
+                            if (OUT & 2) {
+                                u32x4 q0, q1;
+                                split3(a, q0, q1);
+                                unsigned *p = ys + (pvox + k4 * pchunk) * 16 + h * 8;
+                                *reinterpret_cast<u32x4 *>(p) = q0;
+                                *reinterpret_cast<u32x4 *>(p + 4) = q1;
+                            }
+                        }
+                    }
+                }
             }
         }
         CD_STAMP(2);
@@ -1294,6 +1396,8 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
     if (xs && C != 32) return SP3D_EUNSUPPORTED;
     if ((int64_t)X * Y * Z * C * 2 > 0x7fffffff) return SP3D_ERANGE;
     const int NBX = (X + CD_BX - 1) / CD_BX, NBY = (Y + CD_BY - 1) / CD_BY, NBZ = (Z + CD_BZ - 1) / CD_BZ;
+    // 32-bit byte offsets inside one staged region of the zero-bordered split tensor
+    if ((xs || ys) && (int64_t)(CD_RX + 1) * cd_pad(Y, CD_BY) * cd_pad(Z, CD_BZ) * 64 > 0x7fffffff) return SP3D_ERANGE;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
     static int cu_count[64] = {0};                     // per device, queried once (hipGetDeviceProperties is slow)
@@ -1309,7 +1413,7 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
     const int rounds = (int)((blocks + cus - 1) / cus);
     const int nwg = (int)((blocks + rounds - 1) / rounds);
     const dim3 grid((unsigned)nwg), block(64 * (4 + CD_PROD));
-    const size_t lds = (size_t)2 * CD_BUF * sizeof(unsigned) + 4 * 1024 * sizeof(float);
+    const size_t lds = (size_t)2 * CD_BUFS * sizeof(unsigned) + 4 * 1024 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const unsigned *w3 = reinterpret_cast<const unsigned *>(W3), *xs3 = reinterpret_cast<const unsigned *>(xs);
     unsigned *ys3 = reinterpret_cast<unsigned *>(ys);
@@ -1330,6 +1434,15 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
 #undef SP3D_CD
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_conv3_s3_dims(int X, int Y, int Z, int *padded3)
+{
+    using namespace sp3d;
+    if (!padded3) return SP3D_ENULL;
+    if (X <= 0 || Y <= 0 || Z <= 0) return SP3D_EINVAL;
+    padded3[0] = cd_pad(X, CD_BX); padded3[1] = cd_pad(Y, CD_BY); padded3[2] = cd_pad(Z, CD_BZ);
+    return SP3D_OK;
 }
 
 extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,

@@ -1197,9 +1197,9 @@ def test_winograd_split_kernels_confine_nonfinite_inputs(kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims", [(2, (16, 12, 8)), (1, (9, 7, 5)), (1, (40, 24, 10))])
 def test_direct_conv3_split_activation_chain(dims):
-    """two layers chained through the split (S3) activation format: conv1 writes ONLY the S3 tensor, conv2 reads it
-    pre-split and adds the residual - bit-identical to the same two layers through fp32 tensors (the split is exact), and
-    the S3 tensor decodes to conv1's fp32 output bit for bit"""
+    """two layers chained through the split (S3) activation format: conv1 writes ONLY the (zero-bordered, block-padded) S3
+    tensor, conv2 reads it pre-split (LDS-DMA loaders) and adds the residual - bit-identical to the same two layers through
+    fp32 tensors (the split is exact), the S3 tensor decodes to conv1's fp32 output bit for bit, and its border stays zero"""
     from selfpose3d_amd import _lib
     B, (X, Y, Z) = dims
     g = torch.Generator(device="cpu").manual_seed(31)
@@ -1211,9 +1211,15 @@ def test_direct_conv3_split_activation_chain(dims):
     h = _lib.conv3_split_(x, W1, s1, 1)
     want = _lib.conv3_split_(h, W2, s2, 2, x)
     none, h3 = _lib.conv3_split_(x, W1, s1, 1, want_f32=False, want_s3=True)
-    assert none is None and h3.shape == (B, X, Y, Z, 8, 8)
+    PX, PY, PZ = _lib.conv3_s3_dims(X, Y, Z)
+    assert (PX, PY, PZ) == ((X + 15) // 16 * 16 + 2, (Y + 7) // 8 * 8 + 2, (Z + 3) // 4 * 4 + 2)
+    assert none is None and h3.shape == (B, 4, PX, PY, PZ, 2, 8)
+    border = h3.clone()
+    border[:, :, 1:X + 1, 1:Y + 1, 1:Z + 1] = 0
+    assert int(border.abs().max()) == 0
     # decode: dwords [lo01 lo23 hi01 hi23 | hi01 hi23 mid01 mid23], each two bf16 (low half = first channel)
-    d = h3.view(torch.int16).view(B, X, Y, Z, 8, 8, 2).view(torch.bfloat16).float()      # [..., dword, pair]
+    core = h3[:, :, 1:X + 1, 1:Y + 1, 1:Z + 1].permute(0, 2, 3, 4, 1, 5, 6).reshape(B, X, Y, Z, 8, 8).contiguous()
+    d = core.view(torch.int16).view(B, X, Y, Z, 8, 8, 2).view(torch.bfloat16).float()      # [..., dword, pair]
     lo = torch.cat([d[..., 0, :], d[..., 1, :]], -1)
     hi = torch.cat([d[..., 2, :], d[..., 3, :]], -1)
     mid = torch.cat([d[..., 6, :], d[..., 7, :]], -1)
@@ -1223,3 +1229,9 @@ def test_direct_conv3_split_activation_chain(dims):
     assert torch.equal(got, want)
     both = _lib.conv3_split_(x, W1, s1, 1, want_s3=True)
     assert torch.equal(both[0], h) and torch.equal(both[1], h3)
+    # a reused S3 tensor (what the inference plan does): same result, border still zero
+    again = _lib.conv3_split_(None, W2, s2, 2, x, x_s3=h3, want_s3=True, out_s3=got3)
+    assert torch.equal(again[0], want) and again[1] is got3
+    # split input, no fp32 tensor anywhere: the volume's extents come from dims
+    only3 = _lib.conv3_split_(None, W2, s2, 1, None, x_s3=h3, dims=(X, Y, Z))
+    assert torch.equal(only3, _lib.conv3_split_(h, W2, s2, 1))

@@ -10,6 +10,10 @@ if "--build-only" in sys.argv:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call([_b.HIPCC] + _b.FLAGS + ["-DSP3D_CD_TIMELINE", os.path.join(_b.CSRC, "sp3d_winograd.hip"), "-o", LIB])
     subprocess.check_call([_b.HIPCC] + _b.FLAGS + ["-DSP3D_CD_TIMELINE", "-DSP3D_W16_ABLATE=16", os.path.join(_b.CSRC, "sp3d_winograd.hip"), "-o", LIB.replace(".so", "_nostore.so")])
+    for tag, fl in (("_nt", ['-DSP3D_CD_DMA_POLICY=" nt"']), ("_sc", ['-DSP3D_CD_DMA_POLICY=" sc0 sc1"']), ("_same", ["-DSP3D_CD_DMA_SAME"]), ("_sl2", ["-DSP3D_CD_DMA_SLEEP=2"]), ("_sl4", ["-DSP3D_CD_DMA_SLEEP=4"]), ("_sl8", ["-DSP3D_CD_DMA_SLEEP=8"])):
+        if "--only" in sys.argv and tag[1:] not in sys.argv:
+            continue
+        subprocess.check_call([_b.HIPCC] + _b.FLAGS + ["-DSP3D_CD_TIMELINE"] + fl + [os.path.join(_b.CSRC, "sp3d_winograd.hip"), "-o", LIB.replace(".so", tag + ".so")])
     sys.exit(0)
 import torch
 from selfpose3d_amd import _lib
@@ -19,11 +23,12 @@ w = (torch.randn(32, C, 3, 3, 3) * 0.05).cuda()
 W3 = _lib.conv_weights_split(w)
 shift = torch.randn(32).cuda()
 y = torch.empty(B, X, Y, Z, 32, device="cuda")
-L = ctypes.CDLL(LIB.replace(".so", "_nostore.so") if "--no-store" in sys.argv else LIB)
+VAR = [a[6:] for a in sys.argv if a.startswith("--var=")]
+L = ctypes.CDLL(LIB.replace(".so", "_nostore.so") if "--no-store" in sys.argv else (LIB.replace(".so", "_" + VAR[0] + ".so") if VAR else LIB))
 f = L.sp3d_conv3_split_ex
 f.restype = ctypes.c_int
 f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
-x3 = _lib.conv3_split_(x, W3, shift, 1, want_f32=False, want_s3=True)[1] if "--s3" in sys.argv else None
+x3 = _lib.conv3_split_(x, W3, shift, 1, want_f32=False, want_s3=True)[1] if "--s3" in sys.argv else None      # zero-bordered
 tl = torch.zeros(8 * 64 * 4, dtype=torch.int64, device="cuda")
 run = lambda: f(None if x3 is not None else x.data_ptr(), x3.data_ptr() if x3 is not None else None, W3.data_ptr(),
                 y.data_ptr(), None, shift.data_ptr(), None, 1, B, X, Y, Z, C, 32, None)

@@ -38,9 +38,12 @@ for name, (B, C, X, Y, Z, mode) in {} if "--half" in sys.argv else {"root_32_rel
          "direct_bf16x3_us": timeit(lambda: _lib.conv3_split_(x, W3, shift, mode, res))}
     if C == 32:
         x3 = _lib.conv3_split_(x, W3, shift, 1, want_f32=False, want_s3=True)[1]
-        r["direct_s3_in_f32_out_us"] = timeit(lambda: _lib.conv3_split_(None, W3, shift, mode, res, x_s3=x3))
-        r["direct_s3_in_both_out_us"] = timeit(lambda: _lib.conv3_split_(None, W3, shift, mode, res, x_s3=x3, want_s3=True))
-        r["direct_f32_in_s3_out_us"] = timeit(lambda: _lib.conv3_split_(x, W3, shift, mode, res, want_f32=False, want_s3=True))
+        o3 = _lib.conv3_s3_empty(B, X, Y, Z, 32, x.device)          # reused: allocation + zeroing are not part of a layer
+        dm = (X, Y, Z)
+        r["direct_s3_in_f32_out_us"] = timeit(lambda: _lib.conv3_split_(None, W3, shift, mode, res, x_s3=x3, dims=dm))
+        r["direct_s3_in_both_out_us"] = timeit(lambda: _lib.conv3_split_(None, W3, shift, mode, res, x_s3=x3, want_s3=True, out_s3=o3, dims=dm))
+        r["direct_s3_in_s3_out_us"] = timeit(lambda: _lib.conv3_split_(None, W3, shift, mode, res, x_s3=x3, want_f32=False, want_s3=True, out_s3=o3, dims=dm))
+        r["direct_f32_in_s3_out_us"] = timeit(lambda: _lib.conv3_split_(x, W3, shift, mode, res, want_f32=False, want_s3=True, out_s3=o3))
     if B * X * Y * Z <= 600000:
         ref = F.conv3d(x[:1].double(), w.double(), padding=1) + shift.double().view(1, 32, 1, 1, 1)
         if mode == 2:
