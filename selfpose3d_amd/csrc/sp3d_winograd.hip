@@ -925,7 +925,10 @@ struct CdRec { u32x4 hl, hh, mm; };                                    // weight
 
 #ifdef SP3D_CD_TIMELINE
 __device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s_memtime stamps of workgroup 0
-#define CD_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (g_cd_tl && blockIdx.x == 0 && lane == 0 && item < 64) g_cd_tl[(wave * 64 + item) * 4 + (slot)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CD_STAMP(slot) do { __builtin_amdgcn_sched_barrier(0); if (g_cd_tl && blockIdx.x == 0 && lane == 0 && item < 64) { g_cd_tl[(wave * 64 + item) * 4 + (slot)] = __builtin_readcyclecounter(); \
+    /* the constant 100 MHz counter next to the first and the latest stamp of wave 0: cycles per microsecond = the clock the kernel ran at */ \
+    if (wave == 0 && (slot) == 0 && item == 0) { g_cd_tl[(7 * 64 + 62) * 4 + 0] = wall_clock64(); g_cd_tl[(7 * 64 + 62) * 4 + 1] = __builtin_readcyclecounter(); } \
+    if (wave == 0 && (slot) == 3) { g_cd_tl[(7 * 64 + 63) * 4 + 0] = wall_clock64(); g_cd_tl[(7 * 64 + 63) * 4 + 1] = __builtin_readcyclecounter(); } } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define CD_STAMP(slot) do { } while (0)
 #endif

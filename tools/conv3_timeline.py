@@ -39,6 +39,11 @@ assert L.sp3d_debug_conv3_timeline(ctypes.c_void_p(tl.data_ptr())) == 0
 assert run() == 0
 torch.cuda.synchronize()
 t = tl.cpu().view(8, 64, 4)
+w0, c0, w1, c1 = int(t[7, 62, 0]), int(t[7, 62, 1]), int(t[7, 63, 0]), int(t[7, 63, 1])
+t[7, 62] = 0
+t[7, 63] = 0
+if w1 > w0:
+    print(json.dumps({"wall_us_100MHz_counter": (w1 - w0) / 100.0, "s_memtime_ticks": c1 - c0, "ticks_per_us": round((c1 - c0) / ((w1 - w0) / 100.0), 1)}))
 t0 = int(t[t > 0].min())
 rows = []
 for item in range(16):
