@@ -671,8 +671,11 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 // ------------------------------------------------------------------------------------------
 constexpr int BR = 4;
 
+#ifndef SP3D_BRICK_MINW
+#define SP3D_BRICK_MINW 4
+#endif
 template <int JP, bool OUTCL, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(512, 4) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
+__global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
                                                                 const float *__restrict__ centers,
                                                                 const uint8_t *__restrict__ valid,
                                                                 float *__restrict__ cubes, float *__restrict__ grids,

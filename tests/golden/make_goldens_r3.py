@@ -6,6 +6,7 @@ loss modules with ``.cuda()``, lib/models/multi_person_posenet.py:50,81):
   rootnet_48.npz       reference CuboidProposalNet -> V2VNet -> nms at the OTHER shipped grid, 48x48x12
                        (configs/panoptic/resnet50/prn32_cpn48x48x12_960x512_cam5.yaml): pins the generic inference-plan
                        path (no z-DFT / 88x88 plane kernels, other Winograd shapes)
+  rootnet_160.npz      the same at BASELINE configs[3]: 10 views, 160x160x40 (the stress grid: generic plan path at 8x the voxels)
   train_step.npz       reference MultiPersonPoseNet.forward in TRAIN mode on a small scene (lib/models/
                        multi_person_posenet.py:36-102): loss_2d / loss_3d / loss_cord and the gradient of
                        backbone.final_layer.weight, with proposals from the root net and from ground truth (USE_GT)
@@ -60,6 +61,32 @@ def g_rootnet_48():
                         root_abs_sum=np.abs(rc.astype(np.float64)).sum(axis=(1, 2, 3)), nms_vals=vals.numpy(),
                         nms_idx=idx.numpy(), grid_centers=grid_centers.numpy())
     print("rootnet_48: root range", float(rc.min()), float(rc.max()), "top vals", vals.numpy()[:, :5])
+
+
+def g_rootnet_160():
+    """BASELINE configs[3] (the stress configuration): 10 views, 160x160x40 root grid, B=2"""
+    from models.cuboid_proposal_net import CuboidProposalNet
+    from core.proposal import nms
+    img, hm, V, J, cube = (960, 512), (240, 128), 10, 15, (160, 160, 40)
+    cfg = mg.make_cfg(img, hm, syn.SPACE_SIZE, syn.SPACE_CENTER, cube, syn.FINE_GRID_SIZE, (32, 32, 32), J)
+    net = CuboidProposalNet(cfg)
+    syn.fill_parameters_deterministic(net, seed=271, scale=0.05)
+    net.eval()
+    meta = syn.make_meta(2, V, img)
+    hms = mg2.mixed_heatmaps(V, J, hm[1], hm[0], img, seed=273)
+    with torch.no_grad():
+        root_cubes, grid_centers = net(hms, meta)
+        vals, idx = nms(root_cubes, 10)
+    rc = root_cubes.numpy()
+    N = rc[0].size
+    sub = np.arange(0, N, 97)
+    np.savez_compressed(os.path.join(HERE, "rootnet_160.npz"), img=np.array(img), hm=np.array(hm), V=V, J=J, cube=np.array(cube),
+                        hm_seed=273, param_seed=271, param_scale=0.05,
+                        hm_sum=np.array([float(h.double().sum()) for h in hms]), sub_idx=sub,
+                        root_sub=rc.reshape(2, N)[:, sub], root_sum=rc.astype(np.float64).sum(axis=(1, 2, 3)),
+                        root_abs_sum=np.abs(rc.astype(np.float64)).sum(axis=(1, 2, 3)), nms_vals=vals.numpy(),
+                        nms_idx=idx.numpy(), grid_centers=grid_centers.numpy())
+    print("rootnet_160: root range", float(rc.min()), float(rc.max()), "top vals", vals.numpy()[:, :5])
 
 
 def _ref_cfg(ssv=False, **net):
@@ -178,7 +205,7 @@ def g_ssv_train_step():
     print("ssv_train_step:", {k: float(v.mean()) for k, v in losses.items()}, "valid", int((gc[:, :, 3] >= 0).sum()))
 
 
-ALL = {"rootnet_48": g_rootnet_48, "train_step": g_train_step, "ssv_train_step": g_ssv_train_step}
+ALL = {"rootnet_48": g_rootnet_48, "rootnet_160": g_rootnet_160, "train_step": g_train_step, "ssv_train_step": g_ssv_train_step}
 
 if __name__ == "__main__":
     mg2.install_shims()

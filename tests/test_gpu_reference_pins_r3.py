@@ -28,12 +28,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("mode", ["plan_cl", "plan_graph", "eager_plain"])
-def test_rootnet_48x48x12_vs_reference(dev, mode):
+@pytest.mark.parametrize("mode,golden", [("plan_cl", "rootnet_48"), ("plan_graph", "rootnet_48"), ("eager_plain", "rootnet_48"),
+                                         ("plan_cl", "rootnet_160"), ("plan_graph", "rootnet_160")])
+def test_rootnet_other_grids_vs_reference(dev, mode, golden):
+    """48x48x12 (the reference's other shipped YAML) and BASELINE configs[3] (10 views, 160x160x40): CuboidProposalNet
+    end to end against the reference's own run, through the inference plan's GENERIC path at these shapes"""
     from selfpose3d_amd import synthetic as syn
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.cuboid_proposal_net import CuboidProposalNet
-    g = gio.load("rootnet_48")
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", golden + ".npz")):
+        pytest.skip(golden + ".npz not generated")
+    g = gio.load(golden)
     img, hm, V, J = [int(v) for v in g["img"]], [int(v) for v in g["hm"]], int(g["V"]), int(g["J"])
     cube = [int(v) for v in g["cube"]]
     seed = int(g["hm_seed"])

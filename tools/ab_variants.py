@@ -36,7 +36,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--variants", type=str, default="24,56,120")
+    ap.add_argument("--lib", type=str, default=None, help="a measurement build of the library (selfpose3d_amd/ablate/...)")
+    ap.add_argument("--only", type=str, default=None, help="comma list of workloads")
     args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     variants = [int(v) for v in args.variants.split(",")]
     img, (w, h), J = (960, 512), (240, 128), 15
@@ -50,6 +54,8 @@ def main():
         "fine_b10_v4": dict(B=10, V=4, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),
     }
     report = {}
+    if args.only:
+        workloads = {k: v for k, v in workloads.items() if k in args.only.split(",")}
     for name, wl in workloads.items():
         B, V, cube, gs = wl["B"], wl["V"], wl["cube"], wl["gs"]
         N = cube[0] * cube[1] * cube[2]
