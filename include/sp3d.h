@@ -347,6 +347,13 @@ int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shif
  * global_load_lds_dwordx4, no bounds tests, no VALU; ys != NULL (modes 1, 2): the result is ALSO (y != NULL) or ONLY
  * (y == NULL) written as an S3 tensor for the next layer.  16-byte aligned. */
 int sp3d_conv3_s3_dims(int X, int Y, int Z, int *padded3);
+
+/* Batched product of the three-launch Winograd form (sp3d_wino_input -> this -> sp3d_wino_output; replaces the fp32 library
+ * GEMM between them): M[p] (T,O) = V[p] (T,C) . U[p] (C,O) for p < P, fp32 in and out, computed on the bf16 matrix pipe as
+ * exact three-piece splits of both operands (six partial products per multiply, fp32 accumulation).  W3: U as 48-byte
+ * records {hi,lo} {hi,hi} {mid,mid} at index ((p*(C/8) + chunk)*2 + half)*O + o (_lib.wino_gemm_weights_split), 16-byte
+ * aligned.  (C,O) in {(64,128),(128,128)}: the quarter-resolution Res3DBlocks of v2v_net.py:72-110. */
+int sp3d_wino_gemm_split(const float *V, const void *W3, float *M, int P, int T, int C, int O, void *stream);
 int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
                         const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream);
 

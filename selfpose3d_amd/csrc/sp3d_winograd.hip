@@ -904,6 +904,9 @@ __host__ __device__ constexpr int cd_pad(int n, int blk) { return (n + blk - 1) 
 // texture-address queue in front of the consumers' weight loads (prefetched one step = ~1 100 cycles ahead), and the matrix
 // stream then waits for its weights - tap loop 14.0 k cycles per item unthrottled, 12.5 k with 4, 12.3 k with 8 (but then
 // the DMA (13 k) is longer than the item); tools/conv3_timeline.py --s3 --var=sl2|sl4|sl8.
+#ifndef SP3D_WG_ABLATE
+#define SP3D_WG_ABLATE 0
+#endif
 #ifndef SP3D_CD_DMA_SLEEP
 #define SP3D_CD_DMA_SLEEP 4
 #endif
@@ -1289,6 +1292,141 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Batched GEMM of the three-launch Winograd form (quarter-resolution layers, C = 64 | 128 -> O = 128 on 20x20x5): per
+// Winograd point p, M[p] (T x O) = V[p] (T x C) . U[p] (C x O), on the bf16 matrix pipe with exact three-piece splits of both
+// operands (the six products of conv3_split_kernel, fp32 accumulation) instead of rocBLAS on v_mfma_f32_32x32x2_f32
+// (27.7 us per layer = 91 TFLOP/s on 64 x (1200 x 128 x 128)).  Workgroup = one point p, 4 waves = the 4 blocks of 32
+// outputs; a wave keeps ITS weights of every channel chunk in registers for the whole kernel (C/8 x 3 operands = 192 VGPRs at
+// C = 128: one wave per SIMD), the rows go through LDS 128 at a time: all threads load fp32 rows, split them once, and store
+// the two A operands [lo hi] / [hi mid] in separate planes (lane-consecutive 16-byte slots: conflict-free ds_read_b128).
+// W3: the records of conv_weights_split with the point in the place of the tap.
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void wino_gemm_split_kernel(const float *__restrict__ V, const unsigned *__restrict__ W3, float *__restrict__ M, int T, int G)
+{
+    constexpr int C = 8 * NCH, F4 = C / 4, O = 128, ROWS = 128;
+    constexpr int QPLANE = 4 * NCH * 2 * 32;                          // u32x4 slots per operand plane
+    extern __shared__ __attribute__((aligned(16))) u32x4 wg_lds[];    // [q 2][row block 4][chunk NCH][half 2][row 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
+    const int p = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
+    CdRec b[NCH];
+    {
+        const unsigned *wl = W3 + (((int64_t)p * NCH * 2 + h) * O + 32 * wave + t) * 12;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned *r = wl + (int64_t)c * 2 * O * 12;
+#if SP3D_WG_ABLATE & 64
+            (void)r; b[c].hl = u32x4{(unsigned)c, (unsigned)lane, 3u, 4u}; b[c].hh = b[c].hl ^ 5u; b[c].mm = b[c].hl ^ 9u;
+#else
+            b[c].hl = *reinterpret_cast<const u32x4 *>(r);
+            b[c].hh = *reinterpret_cast<const u32x4 *>(r + 4);
+            b[c].mm = *reinterpret_cast<const u32x4 *>(r + 8);
+#endif
+        }
+    }
+    const float *Vp = V + (int64_t)p * T * C;
+    float *Mp = M + (int64_t)p * T * O;
+    const int ntile = (T + ROWS - 1) / ROWS;
+    // staging map: thread -> (row r8 of 8, float4 f4 of the row): a wave reads 8 rows x 128 contiguous bytes, and its
+    // 8 row-consecutive lanes write 8 consecutive 16-byte slots
+    const int r8 = tid & 7, f4 = tid >> 3;
+    constexpr int SU = ROWS / 8;                                       // 16 passes of 8 rows
+    float4 d[SU];
+    auto fetch = [&](int at) {                                         // rows of tile `at`: in flight during the products
+        const int row0 = at * ROWS;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int row = row0 + 8 * u + r8;
+            d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#if SP3D_WG_ABLATE & 32
+            d[u].x = (float)row;
+#else
+            if (f4 < F4 && row < T) d[u] = *reinterpret_cast<const float4 *>(Vp + (int64_t)row * C + 4 * f4);
+#endif
+        }
+    };
+    if (g < ntile) fetch(g);
+    for (int at = g; at < ntile; at += G) {
+        const int row0 = at * ROWS;
+        __syncthreads();                                               // the previous tile's operands have been read
+        if (f4 < F4) {
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int lr = 8 * u + r8;
+                u32x4 q0, q1;
+#if SP3D_WG_ABLATE & 4
+                q0 = u32x4{__float_as_uint(d[u].x), __float_as_uint(d[u].y), __float_as_uint(d[u].z), __float_as_uint(d[u].w)}; q1 = q0 ^ 0x1u;
+#else
+                split3(d[u], q0, q1);
+#endif
+                const int idx = (((lr >> 5) * NCH + (f4 >> 1)) * 2 + (f4 & 1)) * 32 + (lr & 31);
+#if SP3D_WG_ABLATE & 16
+                if (q0.x == 0x12345u)
+#endif
+                {
+                wg_lds[idx] = q0;
+                wg_lds[QPLANE + idx] = q1;
+                }
+            }
+        }
+        __syncthreads();
+        if (at + G < ntile) fetch(at + G);
+        f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+        // consecutive matrix instructions are independent (4 row blocks), operands one chunk ahead
+        u32x4 a0[4], a1[4], n0[4], n1[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = ((m * NCH) * 2 + h) * 32 + t;
+            a0[m] = wg_lds[idx]; a1[m] = wg_lds[QPLANE + idx];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int idx = ((m * NCH + c + 1) * 2 + h) * 32 + t;
+#if SP3D_WG_ABLATE & 8
+                    n0[m] = u32x4{(unsigned)idx, 1u, 2u, (unsigned)c}; n1[m] = n0[m] ^ 3u;
+#else
+                    n0[m] = wg_lds[idx]; n1[m] = wg_lds[QPLANE + idx];
+#endif
+                }
+            }
+#if SP3D_WG_ABLATE & 2
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m][c & 15] += __uint_as_float((a0[m].x ^ b[c].hl.x ^ a1[m].y ^ b[c].hh.z ^ b[c].mm.w) & 0x3fffffffu);
+#else
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a0[m], b[c].hl, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a1[m], b[c].hh, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a1[m], b[c].mm, acc[m]);
+#endif
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { a0[m] = n0[m]; a1[m] = n1[m]; }
+        }
+        // D: lane (column t, h) holds rows 8 (v >> 2) + (v & 3) + 4 h of each row block: 128-byte runs per row
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = row0 + 32 * m + 8 * (v >> 2) + (v & 3) + 4 * h;
+#if SP3D_WG_ABLATE & 1
+                if (acc[m][v] == 123.456f)
+#endif
+                if (row < T) Mp[(int64_t)row * O + 32 * wave + t] = acc[m][v];
+            }
+    }
+}
+
 } // namespace sp3d
 
 extern "C" int sp3d_wino_fused(const float *x, const float *U, float *y, const float *shift, const float *residual, int mode,
@@ -1435,6 +1573,39 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
 #undef SP3D_CDI
 #undef SP3D_CDO
 #undef SP3D_CD
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_wino_gemm_split(const float *V, const void *W3, float *M, int P, int T, int C, int O, void *stream)
+{
+    using namespace sp3d;
+    if (!V || !W3 || !M) return SP3D_ENULL;
+    if (P <= 0 || T <= 0) return SP3D_EINVAL;
+    if (O != 128 || (C != 64 && C != 128) || (reinterpret_cast<uintptr_t>(W3) & 15) || (reinterpret_cast<uintptr_t>(V) & 15))
+        return SP3D_EUNSUPPORTED;
+    if ((int64_t)T * 128 > 0x7fffffff) return SP3D_ERANGE;
+    int dev = 0;
+    { const hipError_t ed = hipGetDevice(&dev); if (ed != hipSuccess) return (int)ed; }
+    if (dev < 0 || dev >= 64) dev = 63;
+    static int cu_count[64] = {0};
+    if (cu_count[dev] == 0) {
+        int n = 0;
+        cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    // one workgroup per CU (its operand planes are 8 KB per channel chunk), an equal share of the points' row tiles each
+    const int ntile = (T + 127) / 128;
+    int G = cu_count[dev] / P;
+    if (G < 1) G = 1;
+    if (G > ntile) G = ntile;
+    const dim3 grid((unsigned)(P * G)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3);
+#define SP3D_WG(NCH_) { const size_t lds = (size_t)2 * 4 * NCH_ * 2 * 32 * 16; static bool attr_dev[64] = {}; bool &attr = attr_dev[dev]; \
+    if (!attr || dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_split_kernel<NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
+    hipLaunchKernelGGL((wino_gemm_split_kernel<NCH_>), grid, block, lds, s, V, w3, M, T, G); }
+    if (C == 128) SP3D_WG(16) else SP3D_WG(8)
+#undef SP3D_WG
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

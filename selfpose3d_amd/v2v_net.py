@@ -236,6 +236,8 @@ class _FoldedV2V:
                     u._sp3d_split = _lib.wino_weights_split(u)
                 elif u is not None and u.shape[2] == 64 and u.shape[1] in (32, 64):
                     u._sp3d_split = _lib.wino_weights_split(u, 16)
+                elif u is not None and u.shape[2] == 128 and u.shape[1] in (64, 128):
+                    u._sp3d_gemm = _lib.wino_gemm_weights_split(u)   # quarter resolution: own split GEMM between the transforms
             if len(blk.skip_con) > 0:
                 ws, ss = self._fold(blk.skip_con[0], blk.skip_con[1])
                 t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws, u1, u2)
@@ -270,7 +272,8 @@ class _FoldedV2V:
                 # (MIOpen) at (4,32->64,40,40,10)
                 return _lib.wino_fused_conv3d_(x, u, shift, mode, residual, u3)
             if C >= 128 or (C >= 64 and 64 * T * C * 4 <= 160e6):
-                return _lib.wino_conv3d_(x, u, shift, mode, residual)
+                w3g = getattr(u, "_sp3d_gemm", None) if getattr(self.net, "wino_split", True) and getattr(self.net, "split_gemm", False) else None
+                return _lib.wino_conv3d_(x, u, shift, mode, residual, w3g)
             w3 = getattr(u, "_sp3d_direct", None) if getattr(self.net, "wino_split", True) and getattr(self.net, "direct_conv", True) else None
             if w3 is not None and C in (16, 32) and u.shape[2] == 32:
                 # implicit GEMM with exact three-piece bf16 splits: no Winograd transforms (which made the fused kernel
@@ -574,6 +577,10 @@ class V2VNet(nn.Module):
         self.zdft = True                 # ... root grid: direct z-DFTs + dense 2-D transforms instead of the 3-D real plans
         self.wino_split = True           # ... fused Winograd layers: exact 3-piece bf16 splits on the bf16 matrix pipe
         self.direct_conv = True          # ... full-resolution 3x3x3 layers: direct (implicit GEMM) split convolution
+        self.split_gemm = False          # ... quarter-resolution Winograd products on the own split-bf16 batched GEMM instead of the
+                                         # library's fp32 one: opt-in, measured 45 vs 36 us (C=128) / 27 vs 39 us (C=64) per product
+                                         # with library heuristics, 27.7 / 25.2 us with TunableOp - the product is memory- and
+                                         # latency-bound at 64 x (1200 x 128 x 128) (tools/bench_wino_gemm.py)
         self.s3_chain = False            # ... chained through split activations (LDS-DMA loaders): measured, no gain - off
         self._plan = None
         self.reset_parameters()

@@ -1235,3 +1235,44 @@ def test_direct_conv3_split_activation_chain(dims):
     # split input, no fp32 tensor anywhere: the volume's extents come from dims
     only3 = _lib.conv3_split_(None, W2, s2, 1, None, x_s3=h3, dims=(X, Y, Z))
     assert torch.equal(only3, _lib.conv3_split_(h, W2, s2, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 1200, 128), (64, 1200, 64), (64, 75, 128), (3, 300, 64), (64, 129, 128)])
+def test_wino_gemm_split_vs_float64(shape):
+    """sp3d_wino_gemm_split (the quarter-resolution Winograd products as exact three-piece bf16 splits, fp32 accumulation)
+    against a float64 product: error <= 1.5x that of the fp32 library GEMM it replaces (+ 1e-7 of the output range), ragged
+    row counts (last 128-row tile partial, fewer rows than one tile) included"""
+    from selfpose3d_amd import _lib
+    P, T, Cc = shape
+    g = torch.Generator(device="cpu").manual_seed(41)
+    V = (torch.randn((P, T, Cc), generator=g) * 2.0).cuda()
+    U = (torch.randn((P, Cc, 128), generator=g) * 0.05).cuda()
+    W3 = _lib.wino_gemm_weights_split(U)
+    M = _lib.wino_gemm_split(V, W3)
+    ref = torch.bmm(V.double(), U.double())
+    lib32 = torch.bmm(V, U)
+    e_own = float((M.double() - ref).abs().max())
+    e_lib = float((lib32.double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert e_own <= 1.5 * e_lib + 1e-7 * scale, (e_own, e_lib, scale)
+    # rows are independent: a row-permuted input gives the row-permuted output bit for bit
+    perm = torch.randperm(T, generator=g).cuda()
+    assert torch.equal(_lib.wino_gemm_split(V[:, perm].contiguous(), W3), M[:, perm])
+
+
+@pytest.mark.gpu
+def test_quarter_resolution_layer_split_gemm_vs_library_gemm():
+    """the three-launch Winograd layer with the split GEMM against the same layer with torch.bmm, both against float64"""
+    from selfpose3d_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(43)
+    x = torch.randn((4, 128, 20, 20, 5), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn((128, 128, 3, 3, 3), generator=g) * 0.03).cuda()
+    shift = torch.randn(128, generator=g).cuda()
+    res = torch.randn((4, 128, 20, 20, 5), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    U = _lib.wino_weights(w)
+    y_own = _lib.wino_conv3d_(x, U, shift, 2, res, _lib.wino_gemm_weights_split(U))
+    y_lib = _lib.wino_conv3d_(x, U, shift, 2, res)
+    ref = (torch.nn.functional.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, -1, 1, 1, 1) + res.double()).clamp_min(0)
+    e_own, e_lib = float((y_own.double() - ref).abs().max()), float((y_lib.double() - ref).abs().max())
+    assert e_own <= 1.5 * e_lib + 1e-7 * float(ref.abs().max()), (e_own, e_lib)
