@@ -933,7 +933,7 @@ __device__ unsigned long long *g_cd_tl = nullptr;      // [wave 6][item 64][4] s
     if (wave == 0 && (slot) == 0 && item == 0) { g_cd_tl[(7 * 64 + 62) * 4 + 0] = wall_clock64(); g_cd_tl[(7 * 64 + 62) * 4 + 1] = __builtin_readcyclecounter(); } \
     if (wave == 0 && (slot) == 3) { g_cd_tl[(7 * 64 + 63) * 4 + 0] = wall_clock64(); g_cd_tl[(7 * 64 + 63) * 4 + 1] = __builtin_readcyclecounter(); } } __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
-#define CD_STAMP(slot) do { } while (0)
+#define CD_STAMP(slot) do { (void)item; } while (0)
 #endif
 
 // a = hi + mid + lo, each a bf16 (exact: 24 mantissa bits), as the two A operands {lo,hi} and {hi,mid} of 4 channels
