@@ -105,14 +105,15 @@ def test_supervised_train_step_vs_reference(dev, tag, deterministic, monkeypatch
     # golden stores as the yardstick.  Pin: this repo's gradient must be about as close to the float64 one as the
     # reference's fp32 gradient is (measured on MI355X with the fixed kernel selection above: 1.06x its error on the 3D
     # term, 5.24x on the pose term, where MIOpen's backward kernels and the fp32 soft-argmax add their own rounding -
-    # 0.9 % of the gradient's magnitude; with find mode it moved between 3x and 18x from process to process; bound: 8x -
-    # a wrong gradient is off by O(1)), and where the problem is well conditioned (2D term, last V2V layer) match the
-    # reference to 1e-4.
+    # 0.9 % of the gradient's magnitude; with find mode - and in immediate mode too, once another test of the same run has
+    # left entries in MIOpen's user db - it moved between 3x and 18x from process to process; bound: 40x = 7 % of the
+    # gradient's magnitude - a wrong gradient (a missing term, a sign) is off by O(1) = 600x), and where the problem is
+    # well conditioned (2D term, last V2V layer) match the reference to 1e-4.
     def close_to_truth(got, name, floor=1e-4):
         ref32, ref64 = g[name], g[name + "_f64"]
         e_ref, e_got = _rel(ref32, ref64), _rel(got, ref64)
         print(f"[{tag}] {name}: error vs float64 {e_got:.3e} (reference fp32: {e_ref:.3e}, ratio {e_got / max(e_ref, 1e-30):.2f})")
-        assert e_got <= max(8.0 * e_ref, floor), (name, e_got, e_ref)
+        assert e_got <= max(40.0 * e_ref, floor), (name, e_got, e_ref)
 
     fl = model.backbone.final_layer.weight
     for nm, term in (("2d", l2d), ("3d", l3d), ("cord", lcord)):
@@ -169,7 +170,7 @@ def test_ssv_train_step_vs_reference(dev, monkeypatch):
                     ("grad_attn_final", model.attn.backbone.final_layer.weight.grad)):
         e = _rel(got.cpu().numpy(), g[nm])
         print(f"[ssv] {nm}: {e:.3e} from the reference's fp32 gradient")
-        assert e <= 2e-3, (nm, e)
+        assert e <= 2e-2, (nm, e)       # measured 7e-5 .. 1.3e-3; the library's kernel choice moves it (see above); wrong = O(1)
 
 
 def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
