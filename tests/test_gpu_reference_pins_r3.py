@@ -163,7 +163,9 @@ def test_ssv_train_step_vs_reference(dev, monkeypatch):
         assert abs(float(v.mean()) - ref) <= 2e-4 * max(abs(ref), 1e-6), (k, float(v.mean()), ref)
     # predicted joints of the second augmented pass (mm)
     ok = g["grid_centers"][:, :, 3] >= 0
-    assert np.abs(pred.cpu().numpy()[ok][..., :3] - g["pred"][ok][..., :3]).max() <= 1.0      # mm, on 2000 mm cubes
+    # mm, on 2000 mm cubes of 62.5 mm voxels: the soft-argmax of a random-weight pose net amplifies the library convolutions'
+    # rounding (measured 0.2-1.6 mm depending on MIOpen's kernel choice); a wrong cube or joint is off by >= a voxel
+    assert np.abs(pred.cpu().numpy()[ok][..., :3] - g["pred"][ok][..., :3]).max() <= 5.0
     sum(v.mean() for v in losses.values() if v.requires_grad).backward()
     for nm, got in (("grad_final", model.backbone.final_layer.weight.grad),
                     ("grad_pose_out", model.pose_net.v2v_net.output_layer.weight.grad),
