@@ -28,15 +28,19 @@
 extern "C" {
 #endif
 
-#define SP3D_ABI_VERSION 1
+#define SP3D_ABI_VERSION 2
 #define SP3D_MAX_VIEWS 16
 #define SP3D_MAX_TOPK 32
 
-/* packed per-(sample, view) camera record: fp32[SP3D_CAM_STRIDE], table shape (B, V, 32).
+/* packed per-(sample, view) camera record: fp32[SP3D_CAM_STRIDE], table shape (B, V, 64).
  * Built on the host by selfpose3d_amd/camera_pack.py::pack_cameras (one upload per call,
  * replacing lib/models/project_layer.py:64-75 + lib/utils/cameras.py:13-24 +
- * lib/utils/transforms.py:61-103 executed per (sample, view) in the reference). */
-#define SP3D_CAM_STRIDE 32
+ * lib/utils/transforms.py:61-103 executed per (sample, view) in the reference).
+ * Fields 0..29 are the camera; fields 32..62 are DERIVED from them (sp3d_camera_finish / camera_pack.finish: call it
+ * again after editing a record by hand): what the packed-fp32 projection reads, laid out for it - operand pairs as
+ * 8-byte aligned neighbours (a scalar-register pair feeds v_pk_*_f32 directly: 13 scalar moves per view and wave less),
+ * the result of the per-view affine sanity test (12 scalar instructions less), all in two 64-byte scalar loads. */
+#define SP3D_CAM_STRIDE 64
 #define SP3D_CAM_R 0      /* [9]  world->camera rotation, row-major            cameras.py:14 */
 #define SP3D_CAM_T 9      /* [3]  camera centre in world, mm  (Xc = R (X - T)) cameras.py:15 */
 #define SP3D_CAM_F 12     /* [2]  fx, fy                                      cameras.py:16-18 */
@@ -48,6 +52,19 @@ extern "C" {
 #define SP3D_CAM_W0 27    /* original image width  = 2*center.x  (project_layer.py:68) */
 #define SP3D_CAM_H0 28    /* original image height = 2*center.y */
 #define SP3D_CAM_FLIP 29  /* 1.0 if flip_xcoords[b] else 0.0      (project_layer.py:82) */
+/* derived block, floats 32..62: everything the packed projection reads, in the order it reads it */
+#define SP3D_CAM_RXY 32   /* [6]  (R00,R10) (R01,R11) (R02,R12) - the x and y rows of R, column by column */
+#define SP3D_CAM_TXY 38   /* [2]  T0, T1 */
+#define SP3D_CAM_RZ 40    /* [3]  R20, R21, R22 */
+#define SP3D_CAM_TZ 43    /*      T2 */
+#define SP3D_CAM_K2 44    /* [3]  k0, k1, k2 */
+#define SP3D_CAM_TAME 47  /*      1.0 if all six |A| <= 1e30 (finite and safe to multiply), else 0.0 */
+#define SP3D_CAM_P2 48    /* [2]  p0, p1 */
+#define SP3D_CAM_F2 50    /* [2]  fx, fy */
+#define SP3D_CAM_C2 52    /* [2]  cx, cy */
+#define SP3D_CAM_WH 54    /* [2]  W0, H0 */
+#define SP3D_CAM_AXY 56   /* [6]  (A00,A10) (A01,A11) (A02,A12) - the affine, column by column */
+#define SP3D_CAM_FLIP2 62 /*      flip */
 
 enum {
     SP3D_OK = 0,
@@ -73,6 +90,10 @@ enum {
 };
 
 int sp3d_abi_version(void);
+
+/* Fill the derived fields (SP3D_CAM_RXY .. SP3D_CAM_FLIP2) of `records` camera records in HOST memory from their fields 0..29.
+ * Pure host arithmetic (copies and one comparison), no device, no stream. */
+int sp3d_camera_finish(float *table_host, int records);
 const char *sp3d_error_string(int code);
 
 /*
@@ -90,7 +111,7 @@ int sp3d_pack_heatmaps_ex(const void *const *hm_views, void *packed, int in_bf16
 /*
  * ProjectLayer.get_voxel forward (project_layer.py:42-102; math: DESIGN.md §3).
  *   hm_views  HOST array of V device pointers, layout per `hm_layout` (Jp used for NHWC only)
- *   cam       (B,V,32) camera table            centers (B,3) grid centres, mm
+ *   cam       (B,V,64) camera table            centers (B,3) grid centres, mm
  *   valid     (B) uint8; 0 => sample skipped: its cubes/grids rows are written as zeros
  *             (project_layer.py:48,51,54: `grid_center[i][3] >= 0`)
  *   cubes     (B,J,X,Y,Z) fp32, z fastest [(B,X,Y,Z,J) with SP3D_OUT_CHANNELS_LAST]
@@ -268,7 +289,7 @@ int sp3d_zdft_inv_cl(const float *spec, float *y, const float *shift, int B, int
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D
  *                                       Gaussian); gx/gy/gz are the fp32 voxel-centre coordinates per axis
  *   sp3d_render_root_heatmaps :205-227  out (V,B,1,h,w) = clip(sum over roots of sigma-3 Gaussians at the roots'
- *                                       projections); cam is the (B,V,32) table whose affine is meta['trans'],
+ *                                       projections); cam is the (B,V,64) table whose affine is meta['trans'],
  *                                       stride = network-input px per heat-map px (the reference's 4.0)
  * roots (B,R,3) fp32 mm, R <= SP3D_MAX_TOPK.  The additive N(0,0.02) noise stays with the caller.
  */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libsp3d_oracle.so")
 _lib = None
 
-CAM_STRIDE = 32
+CAM_STRIDE = 64
 
 
 def build(force: bool = False) -> str:

@@ -22,13 +22,13 @@ HM_BF16 = 0x200
 OUT_BF16 = 0x400
 MAX_VIEWS = 16
 MAX_TOPK = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_conv3_s3_dims", "sp3d_wino_gemm_split", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_conv3_s3_dims", "sp3d_wino_gemm_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -506,7 +506,7 @@ def gaussian_target_3d(roots: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor, 
 
 
 def render_root_heatmaps(roots: torch.Tensor, cam: torch.Tensor, h: int, w: int, stride: float):
-    """roots (B,R,3), cam (B,V,32) -> (V,B,1,h,w) clipped sum of sigma-3 Gaussians at the projected roots"""
+    """roots (B,R,3), cam (B,V,64) -> (V,B,1,h,w) clipped sum of sigma-3 Gaussians at the projected roots"""
     lib = load()
     _require_cuda(roots, "roots")
     B, R = roots.shape[:2]

@@ -4,7 +4,7 @@ The reference does this work inside its batch x view Python loop, with ~6 device
 syncs and one OpenCV call per (sample, view)
 (/root/reference/lib/models/project_layer.py:64-75, lib/utils/transforms.py:61-103,
 lib/utils/cameras.py:13-24).  Here the whole batch is packed in one vectorised numpy pass
-into a (B, V, 32) fp32 table (layout: include/sp3d.h `SP3D_CAM_*`) and uploaded with ONE
+into a (B, V, 64) fp32 table (layout: include/sp3d.h `SP3D_CAM_*`) and uploaded with ONE
 host->device copy; the table is cached while the caller keeps passing the same ``meta``.
 """
 from __future__ import annotations
@@ -14,9 +14,11 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-CAM_STRIDE = 32
+CAM_STRIDE = 64
 # field offsets inside a record (keep in sync with include/sp3d.h)
 CAM_R, CAM_T, CAM_F, CAM_C, CAM_K, CAM_P, CAM_A, CAM_W0, CAM_H0, CAM_FLIP = 0, 9, 12, 14, 16, 19, 21, 27, 28, 29
+# derived block (include/sp3d.h), filled by finish(): what the packed projection reads, in its order
+CAM_RXY, CAM_TXY, CAM_RZ, CAM_TZ, CAM_K2, CAM_TAME, CAM_P2, CAM_F2, CAM_C2, CAM_WH, CAM_AXY, CAM_FLIP2 = 32, 38, 40, 43, 44, 47, 48, 50, 52, 54, 56, 62
 
 
 def _np(x, dtype=None):
@@ -78,7 +80,7 @@ def get_affine_transform_batch(center, scale, rot, output_size) -> np.ndarray:
 
 def pack_cameras(meta: Sequence[dict], batch: int, img_size: Sequence[int],
                  flip_xcoords: Optional[torch.Tensor] = None) -> np.ndarray:
-    """meta: list[V] of collated dicts (App. B of SURVEY.md) -> (B, V, 32) float32 table.
+    """meta: list[V] of collated dicts (App. B of SURVEY.md) -> (B, V, 64) float32 table.
 
     Field semantics per reference line:
       R,T,f,c,k,p  fp32 casts of the camera dict          (cameras.py:13-24)
@@ -112,6 +114,34 @@ def pack_cameras(meta: Sequence[dict], batch: int, img_size: Sequence[int],
         tab[:, c, CAM_H0] = (center[:, 1] * 2.0).astype(np.float32)
         if flips is not None:
             tab[:, c, CAM_FLIP] = flips.astype(np.float32)
+    return finish(tab)
+
+
+def finish(tab: np.ndarray) -> np.ndarray:
+    """fill the DERIVED fields of camera records (..., 48) in place from their fields 0..29 - the numpy twin of the C ABI's
+    sp3d_camera_finish (include/sp3d.h): the packed-fp32 projection's operand pairs as aligned neighbours, and the result of
+    its per-view affine sanity test (every |A| <= 1e30 as an integer comparison of the bit patterns: NaN / inf fail).
+    Call it again after editing a record by hand."""
+    t = tab.reshape(-1, CAM_STRIDE)
+    for c in range(3):
+        t[:, CAM_RXY + 2 * c] = t[:, CAM_R + c]
+        t[:, CAM_RXY + 2 * c + 1] = t[:, CAM_R + 3 + c]
+        t[:, CAM_AXY + 2 * c] = t[:, CAM_A + c]
+        t[:, CAM_AXY + 2 * c + 1] = t[:, CAM_A + 3 + c]
+    t[:, CAM_RZ:CAM_RZ + 3] = t[:, CAM_R + 6:CAM_R + 9]
+    t[:, CAM_K2:CAM_K2 + 3] = t[:, CAM_K:CAM_K + 3]
+    t[:, CAM_TXY:CAM_TXY + 2] = t[:, CAM_T:CAM_T + 2]
+    t[:, CAM_TZ] = t[:, CAM_T + 2]
+    t[:, CAM_P2:CAM_P2 + 2] = t[:, CAM_P:CAM_P + 2]
+    t[:, CAM_F2:CAM_F2 + 2] = t[:, CAM_F:CAM_F + 2]
+    t[:, CAM_C2:CAM_C2 + 2] = t[:, CAM_C:CAM_C + 2]
+    t[:, CAM_WH] = t[:, CAM_W0]
+    t[:, CAM_WH + 1] = t[:, CAM_H0]
+    t[:, CAM_FLIP2] = t[:, CAM_FLIP]
+    mag = np.ascontiguousarray(t[:, CAM_A:CAM_A + 6]).view(np.uint32) & np.uint32(0x7FFFFFFF)
+    t[:, CAM_TAME] = (mag.max(axis=1) <= np.uint32(0x7149F2CA)).astype(np.float32)
+    t[:, 30:32] = 0.0
+    t[:, 63] = 0.0
     return tab
 
 

@@ -52,15 +52,9 @@ __device__ __forceinline__ float umax_f32(float a, float b)
 // and div_const's reciprocal form equals the IEEE division; larger or non-finite rows take the IEEE form.
 __device__ __forceinline__ bool affine_tame(const float *__restrict__ cm)
 {
-    // branch-free on purpose: max of the six magnitudes (as integers) on the scalar unit; the && chain this replaces
-    // compiled to five load + wait + test + branch groups per view
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const uint32_t a = __float_as_uint(cm[SP3D_CAM_A + i]) & 0x7fffffffu;
-        m = a > m ? a : m;
-    }
-    return m <= 0x7149f2cau;                       // 1e30f
+    // computed once per record on the host (sp3d_camera_finish: integer max of the six magnitudes <= 0x7149f2ca = 1e30f);
+    // in the kernel the test was 12 scalar instructions per view and wave
+    return __float_as_uint(cm[SP3D_CAM_TAME]) != 0u;
 }
 
 // inbm: lanes that own a voxel (ballot of `inb`, computed once per wave by the caller)
@@ -69,12 +63,13 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
                                            unsigned long long inbm, P1State &o)
 {
     // --- camera transform + perspective division (cameras.py:40-42); torch's K=3 mm is an fma chain
-    const v2f dxy = v2f{x, y} - v2f{cm[SP3D_CAM_T + 0], cm[SP3D_CAM_T + 1]};
-    const float dz = z - cm[SP3D_CAM_T + 2];
-    v2f c2 = v2f{cm[0], cm[3]} * pk2(dxy.x);
-    c2 = pk_fma(v2f{cm[1], cm[4]}, pk2(dxy.y), c2);
-    c2 = pk_fma(v2f{cm[2], cm[5]}, pk2(dz), c2);
-    const float zc = fmaf(cm[8], dz, fmaf(cm[7], dxy.y, cm[6] * dxy.x));
+    const v2f dxy = v2f{x, y} - v2f{cm[SP3D_CAM_TXY], cm[SP3D_CAM_TXY + 1]};
+    const float dz = z - cm[SP3D_CAM_TZ];
+    // operand pairs from the record's derived block: aligned scalar-register pairs, no moves
+    v2f c2 = v2f{cm[SP3D_CAM_RXY + 0], cm[SP3D_CAM_RXY + 1]} * pk2(dxy.x);
+    c2 = pk_fma(v2f{cm[SP3D_CAM_RXY + 2], cm[SP3D_CAM_RXY + 3]}, pk2(dxy.y), c2);
+    c2 = pk_fma(v2f{cm[SP3D_CAM_RXY + 4], cm[SP3D_CAM_RXY + 5]}, pk2(dz), c2);
+    const float zc = fmaf(cm[SP3D_CAM_RZ + 2], dz, fmaf(cm[SP3D_CAM_RZ + 1], dxy.y, cm[SP3D_CAM_RZ] * dxy.x));
     const float den = zc + 1e-5f;
     v2f yn;
     {   // div_pair (sp3d_device.h) on the pair; one lane out of the reciprocal form's range sends the whole wave through
@@ -98,14 +93,14 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
     float r2 = y2.x + y2.y;
     r2 = fminf(r2, 1e10f);        // NaN r2 -> 1e10, harmless: a NaN yn already makes px,py NaN
     const float r4 = r2 * r2, r6 = r4 * r2;
-    const v2f kr = v2f{cm[SP3D_CAM_K], cm[SP3D_CAM_K + 1]} * v2f{r2, r4};
-    const float radial = 1.0f + ((kr.x + kr.y) + cm[SP3D_CAM_K + 2] * r6);
-    const v2f pt = v2f{cm[SP3D_CAM_P], cm[SP3D_CAM_P + 1]} * v2f{yn.y, yn.x};
+    const v2f kr = v2f{cm[SP3D_CAM_K2], cm[SP3D_CAM_K2 + 1]} * v2f{r2, r4};
+    const float radial = 1.0f + ((kr.x + kr.y) + cm[SP3D_CAM_K2 + 2] * r6);
+    const v2f pt = v2f{cm[SP3D_CAM_P2], cm[SP3D_CAM_P2 + 1]} * v2f{yn.y, yn.x};
     const float tan = pt.x + pt.y;
     const float corr = fmaf(2.0f, tan, radial);       // == radial + 2*tan (2*tan is exact)
-    const v2f u = yn * pk2(corr) + v2f{cm[SP3D_CAM_P + 1], cm[SP3D_CAM_P]} * pk2(r2);
-    v2f p = v2f{cm[SP3D_CAM_F], cm[SP3D_CAM_F + 1]} * u + v2f{cm[SP3D_CAM_C], cm[SP3D_CAM_C + 1]};
-    const float W0 = cm[SP3D_CAM_W0], H0 = cm[SP3D_CAM_H0];
+    const v2f u = yn * pk2(corr) + v2f{cm[SP3D_CAM_P2 + 1], cm[SP3D_CAM_P2]} * pk2(r2);
+    v2f p = v2f{cm[SP3D_CAM_F2], cm[SP3D_CAM_F2 + 1]} * u + v2f{cm[SP3D_CAM_C2], cm[SP3D_CAM_C2 + 1]};
+    const float W0 = cm[SP3D_CAM_WH], H0 = cm[SP3D_CAM_WH + 1];
     // in-image test on the unclamped pixel (project_layer.py:78-79): four compares combined on the scalar unit
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(p.x >= 0.0f) & __builtin_amdgcn_ballot_w64(p.y >= 0.0f) &
                                   __builtin_amdgcn_ballot_w64(p.x < W0) & __builtin_amdgcn_ballot_w64(p.y < H0) & inbm;
@@ -119,11 +114,11 @@ __device__ __forceinline__ bool project_pk(const float *__restrict__ cm, const G
     p.x = clamp_fast(p.x, -1.0f, mx);             // med3: NaN -> lo, so p is finite from here on
     p.y = clamp_fast(p.y, -1.0f, mx);
     // --- crop affine, flip, heat-map coordinate (project_layer.py:81-90, transforms.py:119-123)
-    v2f q = v2f{cm[SP3D_CAM_A + 0], cm[SP3D_CAM_A + 3]} * pk2(p.x);
-    q = pk_fma(v2f{cm[SP3D_CAM_A + 1], cm[SP3D_CAM_A + 4]}, pk2(p.y), q);
-    q = q + v2f{cm[SP3D_CAM_A + 2], cm[SP3D_CAM_A + 5]};             // == fma(A2, 1.0f, q)
+    v2f q = v2f{cm[SP3D_CAM_AXY + 0], cm[SP3D_CAM_AXY + 1]} * pk2(p.x);
+    q = pk_fma(v2f{cm[SP3D_CAM_AXY + 2], cm[SP3D_CAM_AXY + 3]}, pk2(p.y), q);
+    q = q + v2f{cm[SP3D_CAM_AXY + 4], cm[SP3D_CAM_AXY + 5]};         // == fma(A2, 1.0f, q)
     const float W_in = (float)g.W_in, H_in = (float)g.H_in;
-    if (cm[SP3D_CAM_FLIP] != 0.0f) q.x = W_in - q.x;                 // wave-uniform
+    if (cm[SP3D_CAM_FLIP2] != 0.0f) q.x = W_in - q.x;                // wave-uniform
     v2f gn;
     if (__builtin_expect(aff_ok, 1)) {
         // div_const (sp3d_device.h) on the pair: x / c == fma(fma(-q, c, x), rc, q) with q = x * rc

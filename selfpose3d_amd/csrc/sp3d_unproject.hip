@@ -20,6 +20,7 @@
 //                            g * w_tap with hardware fp32 atomics.
 #include <type_traits>
 
+#include <string.h>
 #include "sp3d_device.h"
 #include "sp3d_proj_pk.h"
 #include "sp3d_unproject_patch.h"
@@ -1240,6 +1241,36 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
 using namespace sp3d;
 
 extern "C" int sp3d_abi_version(void) { return SP3D_ABI_VERSION; }
+
+extern "C" int sp3d_camera_finish(float *t, int records)
+{
+    if (!t) return SP3D_ENULL;
+    if (records < 0) return SP3D_EINVAL;
+    for (int r = 0; r < records; ++r, t += SP3D_CAM_STRIDE) {
+        for (int c = 0; c < 3; ++c) {
+            t[SP3D_CAM_RXY + 2 * c] = t[SP3D_CAM_R + c]; t[SP3D_CAM_RXY + 2 * c + 1] = t[SP3D_CAM_R + 3 + c];
+            t[SP3D_CAM_AXY + 2 * c] = t[SP3D_CAM_A + c]; t[SP3D_CAM_AXY + 2 * c + 1] = t[SP3D_CAM_A + 3 + c];
+            t[SP3D_CAM_RZ + c] = t[SP3D_CAM_R + 6 + c];
+            t[SP3D_CAM_K2 + c] = t[SP3D_CAM_K + c];
+        }
+        t[SP3D_CAM_TXY] = t[SP3D_CAM_T]; t[SP3D_CAM_TXY + 1] = t[SP3D_CAM_T + 1]; t[SP3D_CAM_TZ] = t[SP3D_CAM_T + 2];
+        t[SP3D_CAM_P2] = t[SP3D_CAM_P]; t[SP3D_CAM_P2 + 1] = t[SP3D_CAM_P + 1];
+        t[SP3D_CAM_F2] = t[SP3D_CAM_F]; t[SP3D_CAM_F2 + 1] = t[SP3D_CAM_F + 1];
+        t[SP3D_CAM_C2] = t[SP3D_CAM_C]; t[SP3D_CAM_C2 + 1] = t[SP3D_CAM_C + 1];
+        t[SP3D_CAM_WH] = t[SP3D_CAM_W0]; t[SP3D_CAM_WH + 1] = t[SP3D_CAM_H0];
+        t[SP3D_CAM_FLIP2] = t[SP3D_CAM_FLIP];
+        uint32_t m = 0;                     // the per-view test of the projection: every |A| <= 1e30f, as integers (NaN / inf are larger)
+        for (int i = 0; i < 6; ++i) {
+            uint32_t a;
+            memcpy(&a, &t[SP3D_CAM_A + i], 4);
+            a &= 0x7fffffffu;
+            m = a > m ? a : m;
+        }
+        t[SP3D_CAM_TAME] = m <= 0x7149f2cau ? 1.0f : 0.0f;
+        t[30] = t[31] = t[63] = 0.0f;
+    }
+    return SP3D_OK;
+}
 
 extern "C" const char *sp3d_error_string(int code)
 {

@@ -184,7 +184,7 @@ class ProjectLayer(nn.Module):
 
     # -- host side -----------------------------------------------------------------------
     def camera_table(self, meta: Sequence[dict], batch: int, flip_xcoords, device) -> torch.Tensor:
-        """(B,V,32) fp32 table on `device`; rebuilt only when `meta` / flip change.  The upload is one
+        """(B,V,64) fp32 table on `device`; rebuilt only when `meta` / flip change.  The upload is one
         asynchronous copy from a small ring of pinned staging buffers (no host<->GPU synchronisation,
         unlike the ~6 blocking transfers per (sample, view) of the reference, transforms.py:67-72)."""
         if self._static_cam is not None:

@@ -17,7 +17,7 @@ from .camera_pack import CAM_A, CAM_C, CAM_F, CAM_K, CAM_P, CAM_R, CAM_T
 
 def project_joints(joints: torch.Tensor, cam: torch.Tensor, stride: float = 4.0,
                    trans: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """joints (B,P,J,3) world mm, cam (B,V,32) packed table on the same device -> (V,B,P,J,2) heat-map pixels.
+    """joints (B,P,J,3) world mm, cam (B,V,64) packed table on the same device -> (V,B,P,J,2) heat-map pixels.
     ``trans`` (B,2,3): one crop affine for all views of a sample (the reference passes ``meta[0]['trans']``);
     default: the per-view affine of the table."""
     B, V = cam.shape[:2]

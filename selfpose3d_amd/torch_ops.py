@@ -6,7 +6,7 @@ restatement under ``oracle/`` is test infrastructure).
   unproject_fwd(hm, cam, centers, valid, grid_size[3], cube_size[3], img_size[2], hm_size[2], joints=-1)
       -> (cubes (B,J,X,Y,Z), grids (B,N,3))            ProjectLayer.get_voxel, lib/models/project_layer.py:42-102
       hm   (V,B,h,w,Jp) channels-last (Jp in 4/8/12/16, channels >= joints are padding) or (V,B,J,h,w) planar
-      cam  (B,V,32) fp32 table of include/sp3d.h (camera_pack.pack_cameras)
+      cam  (B,V,64) fp32 table of include/sp3d.h (camera_pack.pack_cameras)
       centers (B,3) fp32 mm, valid (B,) uint8 (0 = skipped row, written as zeros, project_layer.py:54)
   unproject_bwd(grad_cubes, hm, cam, centers, valid, grid_size, cube_size, img_size, hm_size, joints=-1)
       -> grad_hm, same shape/layout as hm             autograd of the above w.r.t. the heat-maps

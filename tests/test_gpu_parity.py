@@ -596,7 +596,7 @@ def test_registered_torch_op_forward_and_autograd(dev, layout):
 def test_non_finite_camera_rows_follow_the_reference(dev, field):
     """A non-finite camera / crop row makes every sample position of that view NaN; the reference then zeroes the
     voxel (project_layer.py:98).  The wave-level early-outs of the HIP kernel must not hide that."""
-    from selfpose3d_amd.camera_pack import CAM_A, CAM_F
+    from selfpose3d_amd.camera_pack import CAM_A, CAM_F, finish
     case = gio.Case("unproj_coarse_small")
     cam = case.cam.copy()
     if field == "affine_inf":
@@ -605,7 +605,7 @@ def test_non_finite_camera_rows_follow_the_reference(dev, field):
         cam[0, 1, CAM_A + 5] = np.nan
     else:
         cam[0, 0, CAM_F] = np.nan
-    case.cam = cam
+    case.cam = finish(cam)                  # a record edited by hand: its derived fields follow (include/sp3d.h)
     ref_c, ref_g = _oracle_fwd(case)
     for layout in ("planar", "nhwc"):
         cubes, grids = _hip_fwd(case, dev, layout)

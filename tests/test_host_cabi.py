@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from selfpose3d_amd import _lib, build as sbuild, synthetic as syn
-from selfpose3d_amd.camera_pack import (CAM_A, CAM_FLIP, CAM_H0, CAM_STRIDE, CAM_W0, meta_cache_key, pack_cameras)
+from selfpose3d_amd.camera_pack import (CAM_A, CAM_AXY, CAM_C2, CAM_F2, CAM_FLIP, CAM_FLIP2, CAM_H0, CAM_K2, CAM_P2, CAM_RXY, CAM_RZ,
+                                        CAM_STRIDE, CAM_TAME, CAM_TXY, CAM_TZ, CAM_W0, CAM_WH, finish, meta_cache_key, pack_cameras)
 from selfpose3d_amd.config import default_config, load_config
 from selfpose3d_amd.project_layer import ProjectLayer
 
@@ -31,10 +32,13 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(_lib.EXPORTS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.sp3d_abi_version() == 1
+    assert lib.sp3d_abi_version() == 2               # 2: camera records of 64 floats, the second half derived for the packed projection
     # header constants match the python binding
     for macro, val in (("SP3D_CAM_STRIDE", CAM_STRIDE), ("SP3D_CAM_A", CAM_A), ("SP3D_CAM_W0", CAM_W0),
-                       ("SP3D_CAM_H0", CAM_H0), ("SP3D_CAM_FLIP", CAM_FLIP), ("SP3D_MAX_VIEWS", _lib.MAX_VIEWS),
+                       ("SP3D_CAM_H0", CAM_H0), ("SP3D_CAM_FLIP", CAM_FLIP), ("SP3D_CAM_P2", CAM_P2), ("SP3D_CAM_RXY", CAM_RXY),
+                       ("SP3D_CAM_TXY", CAM_TXY), ("SP3D_CAM_AXY", CAM_AXY), ("SP3D_CAM_TAME", CAM_TAME), ("SP3D_CAM_RZ", CAM_RZ),
+                       ("SP3D_CAM_TZ", CAM_TZ), ("SP3D_CAM_K2", CAM_K2), ("SP3D_CAM_F2", CAM_F2), ("SP3D_CAM_C2", CAM_C2),
+                       ("SP3D_CAM_WH", CAM_WH), ("SP3D_CAM_FLIP2", CAM_FLIP2), ("SP3D_MAX_VIEWS", _lib.MAX_VIEWS),
                        ("SP3D_MAX_TOPK", _lib.MAX_TOPK)):
         m = re.search(r"#define\s+%s\s+(\d+)" % macro, hdr)
         assert m and int(m.group(1)) == val, macro
@@ -100,6 +104,28 @@ def test_camera_table_fields_and_cache_key():
     A = tab[0, 0, CAM_A:CAM_A + 6].reshape(2, 3)
     a = img[0] / (200.0 * float(meta[0]["scale"][0, 0]))
     assert np.allclose(A, [[a, 0, img[0] / 2 - a * 960.0], [0, a, img[1] / 2 - a * 540.0]], atol=1e-5)
+    # derived fields: operand pairs as neighbours + the affine sanity flag; the C ABI's sp3d_camera_finish is the same function
+    assert np.array_equal(tab[..., CAM_RXY:CAM_RXY + 6].reshape(B, V, 3, 2), R[:, :, :2, :].transpose(0, 1, 3, 2))
+    assert np.array_equal(tab[..., CAM_TXY:CAM_TXY + 2], tab[..., 9:11]) and np.array_equal(tab[..., CAM_P2:CAM_P2 + 2], tab[..., 19:21])
+    assert np.array_equal(tab[..., CAM_RZ:CAM_RZ + 3], tab[..., 6:9]) and np.array_equal(tab[..., CAM_TZ], tab[..., 11])
+    assert np.array_equal(tab[..., CAM_K2:CAM_K2 + 3], tab[..., 16:19]) and np.array_equal(tab[..., CAM_F2:CAM_F2 + 4], tab[..., 12:16])
+    assert np.array_equal(tab[..., CAM_WH:CAM_WH + 2], tab[..., 27:29]) and np.array_equal(tab[..., CAM_FLIP2], tab[..., CAM_FLIP])
+    assert np.array_equal(tab[..., CAM_AXY:CAM_AXY + 6].reshape(B, V, 3, 2), tab[..., CAM_A:CAM_A + 6].reshape(B, V, 2, 3).transpose(0, 1, 3, 2))
+    assert np.all(tab[..., CAM_TAME] == 1.0)
+    edited = tab.copy()
+    edited[0, 1, CAM_A + 4] = np.inf
+    edited[1, 2, CAM_A] = np.float32(2e30)
+    edited[2, 0, CAM_A + 2] = np.nan
+    edited[2, 3, CAM_A + 1] = np.float32(-9e29)           # large but tame
+    by_c = edited.copy()
+    by_c[..., 30:] = -7.0                                 # garbage behind the camera fields: the C function overwrites all of it
+    from selfpose3d_amd import _lib as L
+    lib = L.load()
+    assert lib.sp3d_camera_finish(by_c.ctypes.data_as(C.c_void_p), B * V) == 0
+    finish(edited)
+    assert np.array_equal(by_c.view(np.uint32), edited.view(np.uint32))
+    tame = edited[..., CAM_TAME]
+    assert tame[0, 1] == 0.0 and tame[1, 2] == 0.0 and tame[2, 0] == 0.0 and tame[2, 3] == 1.0 and tame.sum() == B * V - 3
     k1 = meta_cache_key(meta, flip, img)
     assert k1 == meta_cache_key(meta, flip, img)
     # the key is the CONTENT of what pack_cameras reads: a value-preserving edit keeps it, any value change - also of
