@@ -67,7 +67,7 @@ def parse():
                     help="leave library-GEMM selection to the rocBLAS/hipBLASLt heuristics (default: opt in to TunableOp "
                          "for the inference plan's GEMMs, V2VNet.tune_gemms(True); recorded in config.gemm_selection)")
     ap.add_argument("--legs", default="auto",
-                    help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, or 'auto' "
+                    help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, unprojection_grids, or 'auto' "
                          "(pose_stage + planar_handover always; train_step = BASELINE configs[2] when --gpus > 1) or 'none'")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-warmup", type=int, default=3)
@@ -383,6 +383,56 @@ def pose_stage_leg(dev, proposals_per_frame=4):
             "persons_per_s": round(B * K / ms * 1e3, 1)}
 
 
+def unprojection_grids_leg(dev, iters=100):
+    """The unprojection kernel alone on the grids of BASELINE configs[3] (10 views -> 160x160x40, B=1), configs[2] (ten
+    64^3 person cubes, 5 views) and configs[4] (3- and 4-view rigs, 64^3 cubes, bf16 heat-maps and cubes): HIP-event time
+    and fraction of the 8 TB/s HBM roofline at SURVEY 8(d)'s algorithmic bytes (2 bytes per element for bf16 tensors)."""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.camera_pack import pack_cameras
+    img, (w, h), J = (960, 512), (240, 128), 15
+    cases = {"configs3_b1_v10_160x160x40": dict(B=1, V=10, cube=(160, 160, 40), gs=syn.SPACE_SIZE, fine=False, bf16=False),
+             "configs2_ten_64cubes_v5": dict(B=10, V=5, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True, bf16=False),
+             "configs4_ten_64cubes_v4_bf16": dict(B=10, V=4, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True, bf16=True),
+             "configs4_ten_64cubes_v3_bf16": dict(B=10, V=3, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True, bf16=True)}
+    out = {}
+    for name, c in cases.items():
+        B, V, cube, gs = c["B"], c["V"], c["cube"], c["gs"]
+        N = cube[0] * cube[1] * cube[2]
+        meta = syn.make_meta(B, V, img)
+        cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
+        if c["fine"]:
+            rng = np.random.default_rng(0)
+            ctr = np.stack([rng.uniform(-1500, 1500, B), rng.uniform(-2000, 1000, B), rng.uniform(700, 1100, B)], 1)
+            centers = torch.from_numpy(ctr.astype(np.float32)).to(dev)
+        else:
+            centers = torch.tensor([syn.SPACE_CENTER] * B, dtype=torch.float32, device=dev)
+        valid = torch.ones(B, dtype=torch.uint8, device=dev)
+        hms = [x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=7)]
+        if c["bf16"]:
+            packed = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
+            views = [packed[i] for i in range(V)]
+            fn = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False,
+                                            out_dtype=torch.bfloat16)
+            alg = 2.0 * B * (V * J * h * w + J * N)
+            what = "bf16 heat-maps and cubes, fp32 arithmetic, planar result"
+        else:
+            packed = _lib.pack_heatmaps(hms, jp=16)
+            views = [packed[i] for i in range(V)]
+            fn = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
+                                            channels_last=True)
+            alg = 4.0 * B * (V * J * h * w + J * N)
+            what = "fp32, channels-last result (what the V2V stack reads)"
+        # the clocks take ~20 ms of load to settle after an idle gap (66.7 -> 57 us over the first 300 launches of the
+        # 160x160x40 kernel): 200 untimed launches, then the median of three timed hundreds
+        event_time_ms(fn, 200, dev)
+        t = float(np.median([event_time_ms(fn, iters, dev) for _ in range(3)]))
+        out[name] = {"kernel_us": round(t * 1e3, 2), "algorithmic_bytes": int(alg),
+                     "achieved_GBps": round(alg / (t * 1e-3) / 1e9, 1), "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "what": what}
+        del packed, views, hms
+    return out
+
+
 def train_step_leg(args, rank, world, dev):
     """BASELINE configs[2]: full train step (ResNet-50 backbone on 5 x 960x512 views, root net 80x80x20 + its loss, pose
     net on 64^3 cubes, Adam), batch 2 per GPU, one process per GPU, DDP gradient all-reduce over RCCL when world > 1.
@@ -486,7 +536,7 @@ def main():
     cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
                                                    not args.no_winograd, args.planar_input, not args.no_gemm_tuning)
     legs = args.legs.split(",") if args.legs not in ("auto", "none") else \
-        ([] if args.legs == "none" else ["pose_stage", "planar_handover"] + (["train_step"] if world > 1 else []))
+        ([] if args.legs == "none" else ["pose_stage", "planar_handover", "unprojection_grids"] + (["train_step"] if world > 1 else []))
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
@@ -621,6 +671,11 @@ def main():
                 extra["pose_stage"] = pose_stage_leg(dev)
             except Exception as e:
                 extra["pose_stage"] = {"error": f"{type(e).__name__}: {e}"}
+        if "unprojection_grids" in legs:
+            try:
+                extra["unprojection_grids"] = unprojection_grids_leg(dev)
+            except Exception as e:
+                extra["unprojection_grids"] = {"error": f"{type(e).__name__}: {e}"}
         result["legs"] = extra
         print(json.dumps(result), flush=True)
         if "output_check" in result and not result["output_check"]["ok"]:
