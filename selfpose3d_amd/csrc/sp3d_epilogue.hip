@@ -213,8 +213,32 @@ __global__ __launch_bounds__(256) void fetch_ring_kernel(const float *__restrict
     __shared__ unsigned int slot;
     if (threadIdx.x == 0) slot = *counter % (unsigned int)R;
     __syncthreads();
-    const volatile float *src = ring + (size_t)slot * n;       // host memory: uncached reads
-    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    // host memory: every load is a PCIe round trip (~2 us), so all of a thread's loads are issued before its first store and
+    // they are 16 bytes wide - one round trip for tables up to 4096 floats (the 64-float camera records of B*V <= 64 views;
+    // dword loads in a dependent loop cost one round trip per 256 floats: 8.6 us for the bench's 1280 floats)
+    const float *src = ring + (size_t)slot * n;
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v *s4 = reinterpret_cast<const f4v *>(src);
+        f4v *d4 = reinterpret_cast<f4v *>(dst);
+        const int n4 = n >> 2;
+        for (int base = 0; base < n4; base += 4 * 256) {
+            f4v v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * 256 + (int)threadIdx.x;
+                if (i < n4) v[k] = __builtin_nontemporal_load(s4 + i);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * 256 + (int)threadIdx.x;
+                if (i < n4) d4[i] = v[k];
+            }
+        }
+    } else {
+        const volatile float *vs = src;
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = vs[i];
+    }
     __syncthreads();
     if (threadIdx.x == 0) *counter = *counter + 1u;
 }
