@@ -1113,9 +1113,15 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
         W3Rec w;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
+#if SP3D_W16_ABLATE & 2
+            // measurement build: no weight loads (what would LDS-broadcast weights be worth at most?)
+            (void)r; w.d[dx].hl = u32x4{0x3f803f80u + (unsigned)q, 0x3f803f80u, 0x3f803f80u + (unsigned)dx, 0x3f803f80u};
+            w.d[dx].hh = w.d[dx].hl ^ 0x00010001u; w.d[dx].mm = w.d[dx].hl ^ 0x00020002u;
+#else
             w.d[dx].hl = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12);
             w.d[dx].hh = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12 + 4);
             w.d[dx].mm = *reinterpret_cast<const u32x4 *>(r + (int64_t)dx * NCH * 2 * O * 12 + 8);
+#endif
         }
         return w;
     };

@@ -30,7 +30,7 @@ if "--build-only" in sys.argv:
     sys.exit(0)
 import torch
 from selfpose3d_amd import _lib
-if "--direct" in sys.argv:         # the direct convolution kernel: 1 no MFMA, 2 no weight loads, 4 no region loads, 8 no LDS reads
+if "--direct" in sys.argv:         # the direct convolution kernel: 2 no weight loads, 16 no result stores
     B, C, X, Y, Z = 4, 32, 80, 80, 20
     x = torch.randn(B, C, X, Y, Z).cuda().contiguous(memory_format=torch.channels_last_3d)
     w = (torch.randn(32, C, 3, 3, 3) * 0.05).cuda()
@@ -38,8 +38,7 @@ if "--direct" in sys.argv:         # the direct convolution kernel: 1 no MFMA, 2
     shift = torch.randn(32).cuda()
     y = torch.empty(B, X, Y, Z, 32, device="cuda")
     out = {}
-    for name, m in {"full": 0, "no_mfma": 1, "no_weight_loads": 2, "no_region_loads": 4, "no_lds_reads": 8,
-                    "mfma_only": 14, "nothing": 15}.items():
+    for name, m in {"full": 0, "no_weight_loads": 2, "no_stores": 16, "no_weight_loads_no_stores": 18}.items():
         L = ctypes.CDLL(lib_path(m))
         f = L.sp3d_conv3_split
         f.restype = ctypes.c_int
