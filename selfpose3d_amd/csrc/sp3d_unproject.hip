@@ -672,6 +672,9 @@ __global__ __launch_bounds__(64 * NW) void unproject_pipe_kernel(Views hm, const
 // ------------------------------------------------------------------------------------------
 constexpr int BR = 4;
 
+#ifndef SP3D_BRICK_U
+#define SP3D_BRICK_U 4          // voxel slots gathered per batch of tap loads (16 dwordx4 in flight at 4)
+#endif
 #ifndef SP3D_BRICK_MINW
 #define SP3D_BRICK_MINW 4
 #endif
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
         float acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-        pipe_views<JP, TI, 4>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, nullptr);
+        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, nullptr);
 
         // view fusion (project_layer.py:96-99) on the gather mapping
         __builtin_amdgcn_wave_barrier();
