@@ -149,6 +149,25 @@ def check_output(out, golden, tol=5e-5):
             "proposal_indices_checked": checked, "proposal_indices_wrong": bad}
 
 
+def use_shipped_miopen_db():
+    """MIOpen searches every new convolution shape once (minutes for the train leg's ~100 shapes on an empty user db).
+    selfpose3d_amd/miopen_db holds the find results of this file's shapes on gfx950 (tools/make_miopen_db.sh): a PRIVATE
+    copy of it becomes this process's user db, so warm-ups start from known results (shapes it does not hold are searched as
+    usual; a MIOpen of another version ignores the files).  Steady-state times are the same either way - it is the search's
+    own result that is cached.  Off with SP3D_NO_SHIPPED_MIOPEN_DB=1 or when MIOPEN_USER_DB_PATH is already set."""
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, "selfpose3d_amd", "miopen_db")
+    if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("SP3D_NO_SHIPPED_MIOPEN_DB") or not os.path.isdir(src):
+        return None
+    dst = tempfile.mkdtemp(prefix="sp3d_miopen_")
+    for f in os.listdir(src):
+        if f.endswith(".txt"):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
+
+
 def event_time_ms(fn, iters, dev):
     """average duration of fn() launched back-to-back on torch's current stream (HIP events)"""
     for _ in range(10):
@@ -532,6 +551,7 @@ def main():
         D.init("nccl", dev)            # backend "nccl" == RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    miopen_db = use_shipped_miopen_db()        # before the first convolution of the process
     torch.backends.cudnn.benchmark = True
     cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
                                                    not args.no_winograd, args.planar_input, not args.no_gemm_tuning)
@@ -627,6 +647,9 @@ def main():
                        "gemm_selection": ("library heuristics" if args.no_gemm_tuning else
                                           "PyTorch TunableOp for the plan's rocBLAS/hipBLASLt GEMMs, opted in by bench.py "
                                           "(V2VNet.tune_gemms(True)); process-wide flags restored after every forward"),
+                       "miopen_user_db": ("private copy of selfpose3d_amd/miopen_db (find results of this file's convolution "
+                                          "shapes: shortens warm-ups, same kernels as a fresh search)" if miopen_db else
+                                          "the process's own (MIOPEN_USER_DB_PATH / default)"),
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
