@@ -179,8 +179,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float
 // stage 2: one workgroup per sample merges nchunks*k candidates (per-wave top-k over a strided share held in registers,
 // then wave 0 merges the four lists), and lanes 0..k-1 unravel their winner and convert it to mm in parallel.
 // Candidate sets beyond NMS_THREADS * MERGE_PER_THREAD are reduced in passes of that size (carry = the running top-k).
-constexpr int MERGE_PER_THREAD = 16;
-
+// candidates per thread and pass: 16 (4096 per pass), or 8 when everything fits one pass of 2048 (the bench's 2000: half the
+// selection work of every round)
+template <int MERGE_PER_THREAD>
 __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict__ ws, int ncand, int X, int Y, int Z,
                                                                int k, float Lx, float Ly, float Lz, float cx, float cy,
                                                                float cz, float *__restrict__ vals,
@@ -367,8 +368,12 @@ extern "C" int sp3d_nms_proposals(const float *root_cubes, int B, int X, int Y, 
     if (e != hipSuccess) return (int)e;
     const float L[3] = {locs ? grid_size[0] : 0.f, locs ? grid_size[1] : 0.f, locs ? grid_size[2] : 0.f};
     const float C[3] = {locs ? grid_center[0] : 0.f, locs ? grid_center[1] : 0.f, locs ? grid_center[2] : 0.f};
-    hipLaunchKernelGGL(nms_merge_kernel, dim3(B), dim3(NMS_THREADS), 0, s, ws, nchunks * k, X, Y, Z, k, L[0], L[1],
-                       L[2], C[0], C[1], C[2], vals, idx, locs, grid_centers, threshold);
+    if (nchunks * k <= NMS_THREADS * 8)
+        hipLaunchKernelGGL(nms_merge_kernel<8>, dim3(B), dim3(NMS_THREADS), 0, s, ws, nchunks * k, X, Y, Z, k, L[0], L[1],
+                           L[2], C[0], C[1], C[2], vals, idx, locs, grid_centers, threshold);
+    else
+        hipLaunchKernelGGL(nms_merge_kernel<16>, dim3(B), dim3(NMS_THREADS), 0, s, ws, nchunks * k, X, Y, Z, k, L[0], L[1],
+                           L[2], C[0], C[1], C[2], vals, idx, locs, grid_centers, threshold);
     e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
