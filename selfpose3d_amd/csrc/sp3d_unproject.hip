@@ -744,10 +744,26 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
         float acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, nullptr);
+#ifdef SP3D_TIMELINE
+        unsigned long long *tl = g_timeline ? g_timeline + ((size_t)blockIdx.x * zw + wave) * 32 : nullptr;
+        SP3D_STAMP_ALWAYS(0);
+        if (tl && lane == 0) tl[26] = wall_clock64();
+#else
+        unsigned long long *tl = nullptr;
+#endif
+        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl);
 
         // view fusion (project_layer.py:96-99) on the gather mapping
         __builtin_amdgcn_wave_barrier();
+        SP3D_STAMP_ALWAYS(30);
+#ifdef SP3D_TIMELINE
+        if (tl && lane == 0) {
+            tl[25] = wall_clock64();
+            tl[28] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+            tl[29] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);
+            tl[31] = (unsigned long long)(mymask & 0x7fffffffu);
+        }
+#endif
         const float den_l = (float)(mymask & 0x7fffffffu) + 1e-6f;
         const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
 #pragma unroll
@@ -781,6 +797,12 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
                 for (int k = 0; k < 4; ++k) ws[(4 * q + k) * WOSTR + 16 * i + g16] = fuse_rcp(acc[i][k], den, rden);
             }
         }
+#ifdef SP3D_TIMELINE
+        if (OUTCL) {
+            __builtin_amdgcn_s_waitcnt(0);                      // the result stores have left the wave
+            if (tl && lane == 0) tl[27] = wall_clock64();
+        }
+#endif
     }
     if (OUTCL) return;
     __syncthreads();

@@ -130,9 +130,12 @@ def needs_find_unused(cfg) -> bool:
     parameter that requires grad gets one on every rank in every iteration, by construction -
     * frozen sub-nets have requires_grad=False (tools/train_3d.py select_trainable, following the reference's
       tools/train_3d.py:48-75; this includes the root net when proposals come from ground truth, USE_GT);
-    * a sub-net that trains but is skipped in an iteration (the pose net when a rank's frames hold no valid proposal)
-      is tied to the loss with zero weight inside the model's forward (engine.zero_anchor), as the reference does with
-      zero-weighted dummy forwards (lib/models/multi_person_posenet_ssv.py:290,429,496,499).
+    * a sub-net that trains but reaches no loss term in an iteration - the pose net when a rank's frames hold no valid
+      proposal, the attention net on the TRAIN_ONLY_2D / TRAIN_ONLY_ROOTNET / INIT_TRAIN_EPOCHS_ROOTNET / SINGLE_AUG return
+      paths, the root net without a 3D target, the backbone when heat-maps are handed in - is tied to the loss with zero
+      weight on EVERY return path of the models' training forwards (engine.anchor_unreached: the models keep the set of
+      sub-nets their loss terms went through), as the reference does with zero-weighted dummy forwards
+      (lib/models/multi_person_posenet_ssv.py:290,429,496,499); tests/test_distributed_gloo.py runs those paths on 2 ranks.
     So the static-graph fast path of DDP applies, and no rank can skip backward() (which would hang the others)."""
     return False
 

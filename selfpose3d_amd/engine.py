@@ -45,6 +45,22 @@ def zero_anchor(params):
     return torch.cat([p.reshape(-1)[:1] for p in ps]).sum() * 0.0
 
 
+def anchor_unreached(term, modules, reached):
+    """term + zero anchors of every sub-net in `modules` ({name: module or None}) whose name is not in `reached`: the
+    models call this on EVERY return path of a training forward with the set of sub-nets their loss terms really went
+    through, so that whatever branch a configuration (or one rank's batch) takes, each trainable parameter is in the
+    graph - DistributedDataParallel(find_unused_parameters=False) needs exactly that, the reference's DataParallel did not
+    care (attention net on the TRAIN_ONLY_* / INIT_TRAIN_EPOCHS_ROOTNET / SINGLE_AUG paths, pose net without 2D
+    targets, root net without 3D targets)."""
+    for name, mod in modules.items():
+        if mod is None or name in reached:
+            continue
+        a = zero_anchor(mod.parameters())
+        if a is not None:
+            term = term + a
+    return term
+
+
 def _to_device(x, dev):
     if isinstance(x, torch.Tensor):
         return x.to(dev, non_blocking=True)

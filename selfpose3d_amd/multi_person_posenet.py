@@ -32,11 +32,6 @@ class MultiPersonPoseNet(nn.Module):
         self.root_id = cfg.DATASET.ROOTIDX
         self.mse = PerJointMSELoss()
         self.l1 = PerJointL1Loss()
-        # benchmark / test hook (None in normal use): callable(grid_centers, meta) -> grid_centers applied AFTER the root
-        # net ran.  A randomly initialised root net proposes nothing near the ground truth, so the pose net would be
-        # skipped; bench.py's train_step leg substitutes the frame's ground-truth roots to time a step with the number of
-        # pose-net passes a trained model has (root net, its loss and its backward still run).
-        self.proposal_override = None
 
     def use_channels_last(self, on: bool = True):
         if not self.train_only_2d:
@@ -82,8 +77,6 @@ class MultiPersonPoseNet(nn.Module):
             if targets_3d is not None:
                 loss_3d = self.mse(root_cubes, targets_3d.to(device))
             del root_cubes
-            if self.proposal_override is not None:
-                grid_centers = self.proposal_override(grid_centers, meta)
 
         pred = torch.zeros(B, self.num_cand, self.num_joints, 5, device=device)
         pred[:, :, :, 3:] = grid_centers[:, :, 3:].reshape(B, -1, 1, 2)          # :77-78
@@ -111,14 +104,20 @@ class MultiPersonPoseNet(nn.Module):
                     count += 1
                     term = self.l1(single[i:i + 1], gt_3d[i:i + 1, g], True, vis[i:i + 1, g, :, 0:1])
                     loss_cord = (loss_cord * (count - 1) + term) / count
-        if count == 0:
-            # no valid proposal (or no ground truth) in this rank's frames: the pose net's parameters must still be in
-            # the graph of the losses, with zero weight, so that every DDP rank runs the same gradient all-reduce
-            # (engine.zero_anchor; the reference's zero-weighted dummy forwards, multi_person_posenet_ssv.py:290,429)
-            from .engine import zero_anchor
-            anchor = zero_anchor(self.pose_net.parameters())
-            if anchor is not None:
-                loss_cord = loss_cord + anchor
+        # Sub-nets no loss term went through in THIS iteration on THIS rank (no valid proposal or no ground truth: pose
+        # net; proposals from ground truth or no 3D target: root net; heat-maps handed in: backbone) are tied to the loss
+        # with zero weight, so that every DDP rank runs the same gradient all-reduce with find_unused_parameters=False
+        # (engine.anchor_unreached; the reference's zero-weighted dummy forwards, multi_person_posenet_ssv.py:290,429)
+        from .engine import anchor_unreached
+        reached = set()
+        if count > 0:
+            reached.add("pose_net")
+        if not self.USE_GT and targets_3d is not None:
+            reached.add("root_net")
+        if views is not None and (targets_2d is not None or reached):
+            reached.add("backbone")
+        loss_cord = anchor_unreached(loss_cord, {"backbone": self.backbone, "root_net": self.root_net,
+                                                 "pose_net": self.pose_net}, reached)
         return pred, all_heatmaps, grid_centers, loss_2d, loss_3d, loss_cord
 
 

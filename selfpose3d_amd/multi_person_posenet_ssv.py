@@ -154,7 +154,7 @@ class MultiPersonPoseNetSSV(nn.Module):
         return pred
 
     def _reprojection_maps(self, pred, count, cam, trans):
-        from .reprojection import project_joints, reprojection_heatmaps
+        from .reprojection import reprojection_heatmaps
         return reprojection_heatmaps(pred[..., :3], count, cam, self.heatmap_height, self.heatmap_width, 4.0, 3.0, trans)
 
     def forward(self, views1=None, meta1=None, targets_2d1=None, weights_2d1=None, targets_3d1=None, input_heatmaps1=None,
@@ -165,7 +165,7 @@ class MultiPersonPoseNetSSV(nn.Module):
             return self.do_inference(views=views1, meta=meta1, input_heatmaps=input_heatmaps1,
                                      visualize_attn=visualize_attn)
         import torch.nn.functional as F
-        from .engine import zero_anchor
+        from .engine import anchor_unreached, zero_anchor
         hm3 = self._heatmaps(views3, input_heatmaps3)                             # set 3: no augmentation (:226-232)
         attns1 = attns2 = None
         if self.WITH_ATTN:                                                       # :234-244
@@ -184,17 +184,29 @@ class MultiPersonPoseNetSSV(nn.Module):
             return zero.clone() if a is None else a
 
         losses = {}
+        # sub-nets some loss term has gone through so far; done() ties the others to loss_2d with zero weight on every
+        # return path (engine.anchor_unreached), so DDP's static-graph mode holds for every flag combination
+        subnets = {"backbone": self.backbone, "attn": self.attn if self.WITH_ATTN else None,
+                   "root_net": getattr(self, "root_net", None), "pose_net": getattr(self, "pose_net", None)}
+        reached = set()
+
+        def done(*ret):
+            losses["loss_2d"] = anchor_unreached(losses["loss_2d"], subnets, reached)
+            return ret
         if targets_2d1 is not None and targets_2d2 is not None:                  # :281-288
             t1 = torch.stack([t.to(device) for t in targets_2d1])
             t2 = torch.stack([t.to(device) for t in targets_2d2])
             t3 = torch.stack([t.to(device) for t in targets_2d3])
             losses["loss_2d"] = (F.mse_loss(t1, torch.stack(list(hm1))) + F.mse_loss(t2, torch.stack(list(hm2))) +
                                  F.mse_loss(t3, torch.stack(list(hm3)))) / 3.0
+            if views1 is not None and views2 is not None and views3 is not None:
+                reached.add("backbone")
         else:
             t1 = t2 = None
             losses["loss_2d"] = anchored(self.backbone)                           # :290
+            reached.add("backbone")
         if self.train_only_2d:
-            return None, hm3, None, losses
+            return done(None, hm3, None, losses)
 
         flip1 = meta1[0].get("hflip") if meta1 is not None else None
         flip2 = meta2[0].get("hflip") if meta2 is not None else None
@@ -220,6 +232,7 @@ class MultiPersonPoseNetSSV(nn.Module):
             losses["loss_root_syn"] = self.weight_root_syn * (F.mse_loss(syn1, tgt1) + F.mse_loss(syn2, tgt2) +
                                                               F.mse_loss(syn3, tgt3))
             main3 = main3.detach()
+            reached.add("root_net")
             if self.root_reg_loss:
                 losses["loss_root_reg"] = self.weight_root_reg * (F.mse_loss(main1, main3) + F.mse_loss(main2, main3))
         else:                                                                    # :331-335
@@ -227,12 +240,14 @@ class MultiPersonPoseNetSSV(nn.Module):
             rc2, _, _, _ = self.root_net(hm2, meta2, flip_xcoords=flip2)
             _, _, _, grid_centers = self.root_net(hm3, meta3, flip_xcoords=flip3)
             losses["loss_root_reg"] = F.mse_loss(rc1, targets_3d1.to(device)) + F.mse_loss(rc2, targets_3d2.to(device))
+            reached.add("root_net")
         if self.train_only_rootnet:
-            return None, hm3, grid_centers, losses
+            return done(None, hm3, grid_centers, losses)
 
         if epoch < self.init_train_epochs_rootnet:                               # :497-499
             losses["loss_pose3d_ssv"] = anchored(self.pose_net)
-            return None, hm3, grid_centers, losses
+            reached.add("pose_net")
+            return done(None, hm3, grid_centers, losses)
 
         from .camera_pack import pack_cameras
         count = (grid_centers[:, :, 3] >= 0).sum(1)                              # valid proposals lead the list (:386)
@@ -245,9 +260,12 @@ class MultiPersonPoseNetSSV(nn.Module):
             if have_people:
                 maps11 = self._reprojection_maps(pred1, count, cam, trans1)
                 losses["loss_pose3d_ssv"] = F.mse_loss(t1, maps11) if t1 is not None else zero.clone()
+                if t1 is not None:
+                    reached.add("pose_net")
             else:
                 losses["loss_pose3d_ssv"] = anchored(self.pose_net)
-            return pred_out, hm3, grid_centers, losses
+                reached.add("pose_net")
+            return done(pred_out, hm3, grid_centers, losses)
 
         pred2 = self._pose_pass(hm2, meta2, grid_centers, flip2)
         pred_out = pred2.detach().clone()
@@ -262,6 +280,10 @@ class MultiPersonPoseNetSSV(nn.Module):
             if t2 is not None:
                 l2 = (F.mse_loss(t2, maps12, reduction="none") * attns2).mean() if self.WITH_ATTN else F.mse_loss(t2, maps12)
             losses["loss_pose3d_ssv"] = l1 + l2
+            if t1 is not None or t2 is not None:
+                reached.add("pose_net")
+            if self.WITH_ATTN:
+                reached.add("attn")
             if self.WITH_ATTN:
                 losses["loss_attn_ssv"] = (F.mse_loss(attns1, torch.ones_like(attns1)) +
                                            F.mse_loss(attns2, torch.ones_like(attns2))) * self.attn_weight
@@ -274,10 +296,12 @@ class MultiPersonPoseNetSSV(nn.Module):
             if self.WITH_ATTN:
                 losses["loss_attn_ssv"] = (F.mse_loss(attns1, torch.ones_like(attns1)) +
                                            F.mse_loss(attns2, torch.ones_like(attns2))) * 0.0
+                reached.add("attn")
             if self.USE_L1 and epoch >= self.L1_EPOCH:
                 losses["loss_pose3d_l1_ssv"] = zero.clone()
             losses["loss_pose3d_ssv"] = anchored(self.pose_net)
-        return pred_out, hm3, grid_centers, losses
+            reached.add("pose_net")
+        return done(pred_out, hm3, grid_centers, losses)
 
 
 def get_multi_person_pose_net(cfg, is_train: bool = True):

@@ -198,3 +198,48 @@ def test_single_process_helpers_are_noops():
     assert torch.equal(D.gather_predictions(t), t)
     m = torch.nn.Linear(2, 2)
     assert D.wrap_ddp(m) is m
+
+
+def _ssv_worker(rank, world, port, q, flags):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from selfpose3d_amd import distributed as D
+    from selfpose3d_amd.engine import train_3d_ssv
+    from selfpose3d_amd.multi_person_posenet_ssv import get_multi_person_pose_net
+    from tests import golden_io as gio
+    D.init("gloo")
+    torch.manual_seed(0)
+    cfg = gio.train_cfg(ssv=True, **flags)
+    cfg.PRINT_FREQ = 100
+    model = get_multi_person_pose_net(cfg, is_train=True)
+    names = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert any(n.startswith("attn.") for n in names)
+    ddp = D.wrap_ddp(model, find_unused=D.needs_find_unused(cfg))
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    batch = gio.train_batch(cfg, B=1, seed=11 + rank, ssv=True)
+    # THREE iterations: DDP(find_unused_parameters=False) raises in the second one if a parameter got no gradient in the first
+    train_3d_ssv(cfg, ddp, opt, [batch, batch, batch], 0, device=torch.device("cpu"))
+    got = {n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    q.put((rank, sorted(names - got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flags", [dict(TRAIN_ONLY_2D=True), dict(USE_GT=True, INIT_TRAIN_EPOCHS_ROOTNET=5)])
+def test_ssv_attention_net_is_anchored_on_early_return_paths(flags):
+    """with WITH_ATTN the attention net runs but reaches no loss on the TRAIN_ONLY_2D / INIT_TRAIN_EPOCHS_ROOTNET
+    (/ TRAIN_ONLY_ROOTNET / SINGLE_AUG) return paths; every trainable parameter must still get a (zero) gradient on every
+    rank in every iteration, or DDP(find_unused_parameters=False) raises on step 2.  CPU-runnable variants of those paths
+    (no unprojection before the return), two ranks, three iterations of the real loop."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ssv_worker, args=(r, world, port, q, flags)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "SSV loop failed or hung under DDP(find_unused_parameters=False)"
+    res = [q.get(timeout=10) for _ in range(world)]
+    assert all(missing == [] for _, missing in res), res

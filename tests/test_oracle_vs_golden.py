@@ -89,3 +89,25 @@ def test_nms_golden_indices_bit_exact():
     vals, idx = oracle.nms_topk(rnd, 10)
     assert np.array_equal(vals, g["rnd_vals"])
     assert np.array_equal(idx, g["rnd_idx"])
+
+
+def test_posenet_full_cubes_golden():
+    """the fine-grid unprojection at the pose stage's full size (5 views, 240x128, J=15, 64^3) against the cubes the
+    reference PoseRegressionNet handed to its V2V (tests/golden/make_goldens_r4.py): 3 valid proposals + 1 skipped"""
+    g = gio.load("posenet_full")
+    img, hm = [int(v) for v in g["img"]], [int(v) for v in g["hm"]]
+    V, J, B = int(g["V"]), int(g["J"]), int(g["B"])
+    cube = [int(v) for v in g["fine_cube"]]
+    N = cube[0] * cube[1] * cube[2]
+    meta = syn.make_meta(B, V, img)
+    hms, _ = syn.people_heatmaps(B, V, J, hm[1], hm[0], img, seed=int(g["hm_seed"]))
+    cam = pack_cameras(meta, B, img)
+    gc = g["grid_centers"]
+    for k in range(gc.shape[1]):
+        valid = (gc[:, k, 3] >= 0).astype(np.uint8)
+        cubes, _ = oracle.unproject_fwd([h.numpy() for h in hms], cam, np.ascontiguousarray(gc[:, k, :3]), valid,
+                                        syn.FINE_GRID_SIZE, cube, img, want_grids=False)
+        got = cubes.reshape(B, J, N)[valid.astype(bool)]
+        assert np.abs(got[:, :, g["sub_idx"]] - g[f"cube_sub_{k}"]).max() <= VOX_TOL
+        assert np.allclose(got.astype(np.float64).sum(axis=2), g[f"cube_sum_{k}"], rtol=0, atol=1e-7 * N)
+        assert np.count_nonzero(cubes[~valid.astype(bool)]) == 0
