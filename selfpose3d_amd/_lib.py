@@ -124,6 +124,20 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise Sp3dError(f"{name} must live on the GPU (got {t.device}); the unprojection path has no CPU fallback")
 
 
+CAM_STRIDE = 64     # floats per (sample, view) record, ABI version 2 (include/sp3d.h: SP3D_CAM_STRIDE)
+
+
+def _require_cam(cam: torch.Tensor, name: str = "cam"):
+    """the kernels read 64-float records (fields 0..29 + the derived block 32..62 written by sp3d_camera_finish /
+    camera_pack.finish): a legacy 32-float table, another dtype or a strided view would be read out of bounds or as
+    garbage WITHOUT any error from the C ABI (it sees a pointer), so the binding refuses them"""
+    _require_cuda(cam, name)
+    if cam.dim() < 2 or cam.shape[-1] != CAM_STRIDE or cam.dtype != torch.float32 or not cam.is_contiguous():
+        raise Sp3dError(f"{name} must be a contiguous float32 (..., {CAM_STRIDE}) camera table built by camera_pack.pack_cameras "
+                        f"(+ camera_pack.finish after edits); got shape {tuple(cam.shape)}, {cam.dtype}, "
+                        f"contiguous={cam.is_contiguous()}")
+
+
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -166,7 +180,7 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
     conv): the planar result is written straight into it (sp3d_unproject_fwd_strided)."""
     lib = load()
     dev = cam.device
-    _require_cuda(cam, "cam")
+    _require_cam(cam)
     X, Y, Z = (int(c) for c in cube_size)
     V = len(views)
     if out is not None:
@@ -215,6 +229,7 @@ def unproject_bwd(hms: Sequence[torch.Tensor], cam, centers, valid, grad_cubes: 
                   img_size, sample_of: Optional[torch.Tensor] = None):
     lib = load()
     dev = cam.device
+    _require_cam(cam)
     B, J, h, w = hms[0].shape
     P = int(grad_cubes.shape[0])
     X, Y, Z = (int(c) for c in cube_size)
@@ -461,6 +476,7 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
     ``deterministic``: accumulate in 64-bit fixed point (integer atomics): bit-identical run to run."""
     lib = load()
     dev = cam.device
+    _require_cam(cam)
     P = int(grad_cubes.shape[0])
     X, Y, Z = (int(c) for c in cube_size)
     gc = grad_cubes[:, :J].float().contiguous()
@@ -509,6 +525,7 @@ def render_root_heatmaps(roots: torch.Tensor, cam: torch.Tensor, h: int, w: int,
     """roots (B,R,3), cam (B,V,64) -> (V,B,1,h,w) clipped sum of sigma-3 Gaussians at the projected roots"""
     lib = load()
     _require_cuda(roots, "roots")
+    _require_cam(cam)
     B, R = roots.shape[:2]
     V = cam.shape[1]
     r = roots.contiguous().float()

@@ -394,7 +394,9 @@ inline void set_xcd_fields(Geom &g, int tiles)
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     g.xm_tiles = tiles;
     g.xm_magic_tiles = (uint32_t)((0x100000000ull / (uint64_t)(tiles > 0 ? tiles : 1)) + 1ull);
-    if (g.B <= 8 && (8 % g.B) == 0) {
+    // the shift-and-mask decode below equals xcd_map() only for a power-of-two chunk size: any other K (no call site
+    // produces one) takes the plain interleave, whose decode is exact for every grid >= B * tiles blocks
+    if (g.B <= 8 && (8 % g.B) == 0 && g.xcd_chunk > 0 && (g.xcd_chunk & (g.xcd_chunk - 1)) == 0) {
         const int xps = 8 / g.B, K = g.xcd_chunk;
         g.xm_mode = 0; g.xm_log2xps = ilog2(xps); g.xm_log2K = ilog2(K);
         g.xm_rows = ((tiles + K - 1) / K + xps - 1) / xps;

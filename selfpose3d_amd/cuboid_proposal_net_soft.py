@@ -158,7 +158,7 @@ class CuboidProposalNetSoft(nn.Module):
     def _render_hip(self, roots, meta, generator=None):
         """GPU path of render_root_heatmaps: one launch for all views (sp3d_render_root_heatmaps)"""
         from . import _lib
-        from .camera_pack import CAM_A, pack_cameras
+        from .camera_pack import CAM_A, finish, pack_cameras
         B = roots.shape[0]
         tab = pack_cameras(meta, B, self.project_layer.img_size)
         trans = meta[0].get("trans")
@@ -166,6 +166,7 @@ class CuboidProposalNetSoft(nn.Module):
             tab[:, :, CAM_A:CAM_A + 6] = trans.detach().cpu().numpy().reshape(B, 1, 6).astype(np.float32)
         else:
             tab[:, :, CAM_A:CAM_A + 6] = tab[:, :1, CAM_A:CAM_A + 6]
+        finish(tab)                                # the derived block follows the edited affine: the table is valid for every kernel
         cam = torch.from_numpy(tab).to(roots.device)
         hm = _lib.render_root_heatmaps(roots, cam, self.hm_h, self.hm_w, self.stride)
         if self.noise_std > 0:

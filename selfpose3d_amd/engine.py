@@ -61,6 +61,16 @@ def anchor_unreached(term, modules, reached):
     return term
 
 
+def _to_host_async(t):
+    """queue ONE device -> pinned-host copy of a small tensor on the current stream (really asynchronous: a pageable
+    destination would make the copy wait for the stream); the caller synchronises before reading"""
+    if not t.is_cuda:
+        return t
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    return host
+
+
 def _to_device(x, dev):
     if isinstance(x, torch.Tensor):
         return x.to(dev, non_blocking=True)
@@ -85,14 +95,17 @@ def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_di
         if config.NETWORK.TRAIN_ONLY_2D:
             loss_2d, _ = model(views=inputs, meta=meta, targets_2d=targets_2d, weights_2d=weights_2d)
             loss = loss_2d.mean()
-            l2d.update(loss.item())
+            parts = [loss]
         else:
             _, _, _, loss_2d, loss_3d, loss_cord = model(views=inputs, meta=meta, targets_2d=targets_2d,
                                                          weights_2d=weights_2d, targets_3d=targets_3d[0])
             loss_2d, loss_3d, loss_cord = loss_2d.mean(), loss_3d.mean(), loss_cord.mean()
-            l2d.update(loss_2d.item()); l3d.update(loss_3d.item()); lcord.update(loss_cord.item())
             loss = loss_2d + loss_3d + loss_cord                                  # function.py:279
-        losses.update(loss.item())
+            parts = [loss_2d, loss_3d, loss_cord, loss]
+        # the meters' values leave the device in ONE asynchronous copy, read after backward + step were queued (the
+        # reference's four .item() calls per iteration, function.py:262-281, each stall the stream)
+        stacked = torch.stack([p.detach().float() for p in parts])
+        host = _to_host_async(stacked)
         optimizer.zero_grad(set_to_none=True)
         if not loss.requires_grad:
             # nothing trainable was reached on THIS rank: backward() must run all the same (see zero_anchor); the models
@@ -103,6 +116,14 @@ def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_di
         if loss.requires_grad:
             loss.backward()
             optimizer.step()
+        if stacked.is_cuda:
+            torch.cuda.current_stream(stacked.device).synchronize()
+        vals = host.tolist()
+        if len(vals) == 1:
+            l2d.update(vals[0])
+        else:
+            l2d.update(vals[0]); l3d.update(vals[1]); lcord.update(vals[2])
+        losses.update(vals[-1])
         bt.update(time.time() - end)
         end = time.time()
         if i % int(config.PRINT_FREQ) == 0:
@@ -149,17 +170,27 @@ def train_3d_ssv(config, model, optimizer, loader, epoch, output_dir=None, write
                                    views3=in3, meta3=meta3, targets_2d3=t2d3, weights_2d3=w2d3, targets_3d3=t3d3[0],
                                    epoch=epoch)
         terms = [v.mean() for v in loss_dict.values() if v.requires_grad]        # :107
-        for k, v in loss_dict.items():
-            meters[k].update(float(v.mean()))
         optimizer.zero_grad(set_to_none=True)
         if not terms:                                                            # every rank must run backward (zero_anchor)
             anchor = zero_anchor(net.parameters())
             terms = [] if anchor is None else [anchor]
-        if terms:
-            loss = sum(terms)
-            meters["losses"].update(loss.item())
+        loss = sum(terms) if terms else None
+        # ONE device -> host transfer per iteration for all the meters (the reference reads every term with .item(),
+        # function.py:109-131: up to seven stream-serialising syncs per step), issued before backward so that it overlaps it
+        keys = list(loss_dict.keys())
+        stacked = torch.stack([loss_dict[k].detach().mean().float() for k in keys] +
+                              ([loss.detach().float()] if loss is not None else []))
+        host = _to_host_async(stacked)
+        if loss is not None:
             loss.backward()
             optimizer.step()
+        if stacked.is_cuda:
+            torch.cuda.current_stream(stacked.device).synchronize()
+        vals = host.tolist()
+        for k, v in zip(keys, vals):
+            meters[k].update(v)
+        if loss is not None:
+            meters["losses"].update(vals[-1])
         bt.update(time.time() - end)
         end = time.time()
         if i % int(config.PRINT_FREQ) == 0:

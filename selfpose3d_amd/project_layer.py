@@ -171,6 +171,7 @@ class ProjectLayer(nn.Module):
         """Inside the context every call uses ``table`` (a device tensor the caller refreshes itself) and re-tiles
         the heat-maps on every call: what HIP-graph capture of a forward needs (graphs.py).  Everything is restored
         on exit, so eager calls after a capture behave as before."""
+        _lib._require_cam(table, "static camera table")
         prev = (self._static_cam, self.cache_packs)
         self._static_cam, self.cache_packs = table, False
         try:

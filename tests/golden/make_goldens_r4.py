@@ -32,25 +32,8 @@ import make_goldens as mg        # noqa: E402
 import make_goldens_r2 as mg2    # noqa: E402
 from selfpose3d_amd import synthetic as syn   # noqa: E402
 
-POSENET_FULL = dict(img=(960, 512), hm=(240, 128), V=5, J=15, B=2, fine_cube=(64, 64, 64), hm_seed=411, pose_seed=413,
-                    param_scale=0.05, stride=211)
-
-
-def posenet_full_inputs(device="cpu"):
-    """heat-maps, meta and the (B, K=2, 5) proposal table of the posenet_full case (shared with the tests)"""
-    c = POSENET_FULL
-    meta = syn.make_meta(c["B"], c["V"], c["img"])
-    hms, pts = syn.people_heatmaps(c["B"], c["V"], c["J"], c["hm"][1], c["hm"][0], c["img"], seed=c["hm_seed"], device=device)
-    gc = np.zeros((c["B"], 2, 5), np.float32)
-    off = np.array([[37.0, -21.0, 55.0], [-44.0, 62.0, -18.0]], np.float32)
-    for b in range(c["B"]):
-        for k in range(2):
-            root = pts[b][k % pts[b].shape[0], 2]                 # the person's root joint (ROOTIDX = 2)
-            gc[b, k, :3] = root.astype(np.float32) + off[k]
-            gc[b, k, 3] = 0.0
-            gc[b, k, 4] = 0.9 - 0.1 * k
-    gc[1, 1, 3] = -1.0                                            # the invalid proposal: skipped by ProjectLayer and the V2V
-    return hms, meta, torch.from_numpy(gc).to(device)
+import golden_io as gio          # noqa: E402
+POSENET_FULL, posenet_full_inputs = gio.POSENET_FULL, gio.posenet_full_inputs
 
 
 def g_posenet_full():

@@ -118,3 +118,28 @@ def he_fill(model, seed):
                 a = 0.05 * rng.standard_normal(tuple(t.shape)).astype(np.float32)
             t.copy_(torch.from_numpy(a))
     return model
+
+
+# ---- round 4: the pose stage at full size (tests/golden/make_goldens_r4.py) --------------------------------------------
+POSENET_FULL = dict(img=(960, 512), hm=(240, 128), V=5, J=15, B=2, fine_cube=(64, 64, 64), hm_seed=411, pose_seed=413,
+                    param_scale=0.05, stride=211)
+
+
+def posenet_full_inputs(device="cpu"):
+    """heat-maps, meta and the (B, K=2, 5) proposal table of the posenet_full case (generator, tests and bench.py's
+    pose_stage check all build them here): the synthetic people scene, proposal centres near (not on) two people's roots,
+    sample 1 of slot 1 invalid (flag < 0)"""
+    from selfpose3d_amd import synthetic as syn
+    c = POSENET_FULL
+    meta = syn.make_meta(c["B"], c["V"], c["img"])
+    hms, pts = syn.people_heatmaps(c["B"], c["V"], c["J"], c["hm"][1], c["hm"][0], c["img"], seed=c["hm_seed"], device=device)
+    gc = np.zeros((c["B"], 2, 5), np.float32)
+    off = np.array([[37.0, -21.0, 55.0], [-44.0, 62.0, -18.0]], np.float32)
+    for b in range(c["B"]):
+        for k in range(2):
+            root = pts[b][k % pts[b].shape[0], 2]                 # the person's root joint (ROOTIDX = 2)
+            gc[b, k, :3] = root.astype(np.float32) + off[k]
+            gc[b, k, 3] = 0.0
+            gc[b, k, 4] = 0.9 - 0.1 * k
+    gc[1, 1, 3] = -1.0                                            # the invalid proposal: skipped by ProjectLayer and the V2V
+    return hms, meta, torch.from_numpy(gc).to(device)

@@ -60,3 +60,36 @@ def test_cpu_reference_record_and_defaults():
         sys.argv = argv
     assert (a.gpus, a.batch) == (1, 4) and a.steps >= 20 and a.warmup >= 1 and not a.planar_input
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_gpus_flag_never_runs_fewer_ranks_silently(monkeypatch):
+    """round-3 review: `python bench.py --gpus 8` ran ONE rank and printed n_gpus = 1.  Now: without a launcher it re-execs
+    itself under torch.distributed.run with --nproc-per-node N on 127.0.0.1 (or refuses when the box has fewer GPUs), and
+    with a launcher the world size must equal --gpus."""
+    import pytest
+    bench = _bench()
+    # (a) no launcher, not enough GPUs: loud refusal (this container has none)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "--gpus 8" in str(e.value) and "GPU(s) visible" in str(e.value)
+    # (b) no launcher, --share-gpu (or enough GPUs): the exec'd command is the task statement's launch line
+    seen = {}
+
+    def fake_execv(exe, cmd):
+        seen["cmd"] = cmd
+        raise SystemExit("exec")
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--share-gpu", "--steps", "3"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["--gpus", "2", "--share-gpu", "--steps", "3"]
+    # (c) launcher with another world size: refused, never a line with the wrong n_gpus
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value)

@@ -1,0 +1,36 @@
+"""The whole multi-rank code path of bench.py on ONE GPU (round-3 review, item 3c): `python bench.py --gpus 2 --share-gpu`
+launches itself under torch.distributed.run (2 ranks on 127.0.0.1), both ranks on cuda:0, process group gloo with CUDA tensors:
+frames sharded by rank, max-over-ranks timing, the DDP train_step leg with its gradient all-reduce - what the CPU gloo tests
+cannot see (private MIOpen db directory per rank, TunableOp files, HIP-graph capture in two processes, port choice).  RCCL
+itself needs >= 2 GPUs and is the driver's run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_share_one_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
+           "--roofline-iters", "20", "--no-cpu-baseline", "--no-cold", "--no-fp32-leg", "--legs", "train_step",
+           "--train-steps", "1", "--train-warmup", "1", "--train-find", "immediate"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints the ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0
+    assert "SMOKE" in rec["config"]["parallelism"] and rec["output_check"]["ok"]
+    ts = rec["legs"]["train_step"]
+    assert "error" not in ts, ts
+    assert ts["n_gpus"] == 2 and ts["allreduce_bytes_per_step"] == ts["gradient_bytes"] > 100e6
+    assert ts["find_unused_parameters"] is False and ts["value"] > 0 and ts["loss_last"] == ts["loss_last"]

@@ -94,8 +94,16 @@ def main():
                                                          cube, gs, img, False, out_dtype=torch.bfloat16)
         fns["pack_bf16"] = lambda: _lib.pack_heatmaps(hms, jp=16, out=packed16)
         times = {k: [] for k in fns}
+        ref_out = None
         for k, fn in fns.items():
             timed(fn, 5)
+            if k.endswith("_cl"):                   # every channels-last variant must produce the same bits
+                out = fn()[0]
+                torch.cuda.synchronize()
+                if ref_out is None:
+                    ref_out = out.clone()
+                else:
+                    assert torch.equal(out, ref_out), f"variant {k} differs from the default on {name}"
         for _ in range(args.rounds):
             for k, fn in fns.items():
                 times[k].append(timed(fn, args.iters if k != "planar" else max(5, args.iters // 10)))

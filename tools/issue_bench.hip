@@ -30,7 +30,7 @@ static const char *kind_name[] = {"v_fma_f32 (8 independent)", "v_pk_fma_f32 (8 
 // instructions per REP64 body, by kind
 static int body_insts(int k) { return (k == K_MIX_VS) ? 128 : (k == K_MIX_VSN) ? 192 : 64; }
 
-struct Stamp { unsigned long long t0, t1, w0, w1; unsigned hw, kind; };
+struct Stamp { unsigned long long t0, t1, w0, w1; unsigned hw, kind, xcc, pad; };
 
 __device__ __forceinline__ unsigned long long wall() { return wall_clock64(); }
 
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(1024) void bench_kernel(Stamp *st, int iters, float
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long w1 = wall();
     if (lane == 0) {
-        Stamp s; s.t0 = t0; s.t1 = t1; s.w0 = w0; s.w1 = w1; s.hw = __builtin_amdgcn_s_getreg(63492); s.kind = second ? KB : KA;
+        Stamp s; s.t0 = t0; s.t1 = t1; s.w0 = w0; s.w1 = w1; s.hw = __builtin_amdgcn_s_getreg(63492); s.kind = second ? KB : KA; s.xcc = __builtin_amdgcn_s_getreg(63508); s.pad = 0;
         st[blockIdx.x * (blockDim.x >> 6) + wave] = s;
     }
     if (sink == 123.456f) out[0] = sink + (float)lds_floats;
 }
 
-struct Row { std::string name; int wps; double cpi_simd; double cpi_wave; double mhz; std::string note; };
+struct Row { std::string name; int wps; double cpi_simd; double cpi_wave; double mhz; std::string note; double resident; };
 static std::vector<Row> rows;
 
 template <int KA, int KB>
@@ -159,22 +159,45 @@ static void run(const char *label, int waves_per_simd, int iters = 200)
         const double wallticks = (double)(s.w1 - s.w0);       // 100 MHz
         if (wallticks > 100) { mhz += cyc / (wallticks / 100.0); ++nm; }
     }
+    // how many waves really shared a SIMD: per (XCC, SE, SH, CU, SIMD) the waves whose wall-clock interval covers the middle
+    // of the first-listed wave's interval (two 1024-thread workgroups per CU are asked for at 8 waves / SIMD: did both fit?)
+    double resident = 0; int nres = 0;
+    {
+        std::vector<std::pair<unsigned long long, size_t>> key;
+        for (size_t i = 0; i < h.size(); ++i) {
+            const unsigned hw = h[i].hw;    // HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+            const unsigned long long k = ((unsigned long long)(h[i].xcc & 0xf) << 32) | ((hw >> 8) & 0xff) << 8 | ((hw >> 4) & 3);
+            key.push_back({k, i});
+        }
+        std::sort(key.begin(), key.end());
+        for (size_t a = 0; a < key.size();) {
+            size_t b = a;
+            while (b < key.size() && key[b].first == key[a].first) ++b;
+            const Stamp &r = h[key[a].second];
+            const unsigned long long mid = (r.w0 + r.w1) / 2;
+            int c = 0;
+            for (size_t j = a; j < b; ++j) { const Stamp &q = h[key[j].second]; if (q.w0 <= mid && q.w1 >= mid) ++c; }
+            resident += c; ++nres;
+            a = b;
+        }
+    }
     auto med = [](std::vector<double> &v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     const double ca = med(cw[0]), cb = med(cw[1]);
-    Row r; r.name = label; r.wps = waves_per_simd; r.mhz = nm ? mhz / nm : 0;
+    Row r; r.name = label; r.wps = waves_per_simd; r.mhz = nm ? mhz / nm : 0; r.resident = nres ? resident / nres : 0;
+    const double wres = r.resident > 0 ? r.resident : waves_per_simd;      // divide by what was really co-resident
     char note[256];
     if (KA == KB) {
-        r.cpi_wave = ca; r.cpi_simd = ca / waves_per_simd;
+        r.cpi_wave = ca; r.cpi_simd = ca / wres;
         snprintf(note, sizeof note, "%s", "");
     } else {
         // half the waves of a SIMD run KA, half KB, concurrently
-        const int half = waves_per_simd / 2;
+        const double half = wres / 2;
         r.cpi_wave = ca; r.cpi_simd = 0;
         snprintf(note, sizeof note, "A-waves %.2f cyc/inst each (=> %.2f per SIMD for the A class), B-waves %.2f (=> %.2f)", ca, ca / half, cb, cb / half);
     }
     r.note = note;
     rows.push_back(r);
-    printf("%-58s waves/SIMD=%d  cyc/inst per wave %6.2f  per SIMD %6.2f  clock %.0f MHz  %s\n", label, waves_per_simd, r.cpi_wave, r.cpi_simd, r.mhz, note);
+    printf("%-58s waves/SIMD asked %d resident %.2f  cyc/inst per wave %6.2f  per SIMD %6.2f  clock %.0f MHz  %s\n", label, waves_per_simd, r.resident, r.cpi_wave, r.cpi_simd, r.mhz, note);
     fflush(stdout);
     hipFree(st); hipFree(out); hipFree(hot);
 }
@@ -204,8 +227,8 @@ int main(int argc, char **argv)
     run<K_FMA, K_PKFMA>("A = v_fma_f32 waves, B = v_pk_fma_f32 waves", 4);
     run<K_SALU, K_SNOP>("A = s_add_u32 waves, B = s_nop waves", 4);
     if (md) {
-        printf("\n| stream | waves / SIMD | cycles per instruction, one wave | cycles per instruction, per SIMD | clock MHz | note |\n|---|---:|---:|---:|---:|---|\n");
-        for (auto &r : rows) printf("| %s | %d | %.2f | %s | %.0f | %s |\n", r.name.c_str(), r.wps, r.cpi_wave,
+        printf("\n| stream | waves / SIMD asked | resident (measured) | cycles per instruction, one wave | cycles per instruction, per SIMD | clock MHz | note |\n|---|---:|---:|---:|---:|---:|---|\n");
+        for (auto &r : rows) printf("| %s | %d | %.2f | %.2f | %s | %.0f | %s |\n", r.name.c_str(), r.wps, r.resident, r.cpi_wave,
                                     r.cpi_simd > 0 ? (std::to_string(r.cpi_simd).substr(0, 5)).c_str() : "-", r.mhz, r.note.c_str());
     }
     return 0;

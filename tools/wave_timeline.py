@@ -87,4 +87,42 @@ res = {"waves": int(len(t)), "kernel_us_event": round(us, 1), "kernel_span_ticks
        "wait_fma_ticks_mean": [float((nxt(c) - t[:, 4 + 4 * c]).mean()) for c in range(V)],
        "start_spread_ticks": {"p50": float(np.percentile(start - start.min(), 50)), "p90": float(np.percentile(start - start.min(), 90)), "max": float((start - start.min()).max())},
        "life_by_bound_views": {int(k): float(life[t[:, 31] == k].mean()) for k in np.unique(t[:, 31])}}
+# phase concurrency per CU (round 4): how many of a CU's resident waves are in the SAME phase at the same instant?
+# (cycle counters are per XCD: compare waves of one XCD only).  issue = [view start, tap loads issued), p1 = [loads issued,
+# next view projected), fma = [projected, next view start)
+xcc = (t[:, 29] & 0xf).astype(int)
+hw = t[:, 28].astype(np.int64)
+cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7)
+m = xcc == 0
+tt, cux = t[m].astype(np.float64), cu[m]
+# the cycle counters are not aligned between CUs: place every wave on the chip-wide 100 MHz clock (stamp 26 = wave start)
+# and measure inside the wave with its own cycle counter
+fclk = float(np.median((tt[:, 30] - tt[:, 0]) / np.maximum(1.0, (tt[:, 25] - tt[:, 26]))))      # cycles per 10 ns
+base = tt[:, 26] * fclk - tt[:, 0]
+for col in list(range(0, 25)) + [30]:
+    tt[:, col] = np.where(tt[:, col] > 0, tt[:, col] + base, 0.0)
+res["cycles_per_us"] = round(fclk * 100.0, 1)
+iv = {"issue": [], "p1": [], "fma": []}
+for c in range(V):
+    s0, s1, s2 = tt[:, 2 + 4 * c], tt[:, 3 + 4 * c], tt[:, 4 + 4 * c]
+    s3 = tt[:, 2 + 4 * (c + 1)] if c + 1 < V else tt[:, 30]
+    ok = (s0 > 0) & (s1 >= s0) & (s2 >= s1) & (s3 >= s2)
+    for k, (a, b) in (("issue", (s0, s1)), ("p1", (s1, s2)), ("fma", (s2, s3))):
+        iv[k].append(np.stack([a[ok], b[ok], cux[ok]], 1))
+iv = {k: np.concatenate(v) for k, v in iv.items()}
+t0, t1 = tt[:, 0].min(), tt[:, 30].max()
+grid = np.linspace(t0 + 0.1 * (t1 - t0), t0 + 0.6 * (t1 - t0), 400)         # the busy middle of the launch
+conc = {}
+for k, v in iv.items():
+    counts = []
+    for c_ in sorted(set(cux.tolist()))[:32]:
+        r = v[v[:, 2] == c_]
+        counts.append([int(((r[:, 0] <= g_) & (r[:, 1] > g_)).sum()) for g_ in grid])
+    counts = np.array(counts)
+    conc[k] = {"mean_waves_in_phase_per_cu": round(float(counts.mean()), 2), "p10": float(np.percentile(counts, 10)),
+               "p50": float(np.percentile(counts, 50)), "p90": float(np.percentile(counts, 90)), "max": int(counts.max()),
+               "mean_phase_ticks": round(float((v[:, 1] - v[:, 0]).mean()), 1)}
+live = np.array([[int(((tt[cux == c_, 0] <= g_) & (tt[cux == c_, 30] > g_)).sum()) for g_ in grid] for c_ in sorted(set(cux.tolist()))[:32]])
+res["phase_concurrency_xcd0"] = conc
+res["resident_waves_per_cu_mean_in_window"] = round(float(live.mean()), 2)
 print(json.dumps(res, indent=1))
