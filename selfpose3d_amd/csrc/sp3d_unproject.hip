@@ -829,6 +829,221 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 heat-maps (BASELINE configs[4]) on bricks with TWO lanes per pixel (round 4).
+//
+// The fp32 kernels give a 64-byte pixel to 4 lanes (16 B each).  With bf16 storage the same mapping loads 8 B per lane:
+// half the bytes, the SAME 16 tap wave-loads per view - and the gather is bound by wave-loads through the texture path and
+// by L1 line fills, not by bytes (profiles/r04_issue_model.md), so bf16 storage bought nothing and the conversion made it
+// slower than fp32 (99.5 vs 90.3 us, ten 64^3 cubes, 4 views).  Here a 32-byte bf16 pixel goes to 2 lanes, 16 B = 8 channels
+// each: a wave-load covers 32 voxels instead of 16, a view needs 8 wave-loads instead of 16, and every lane still owns 16
+// accumulators (2 voxel slots x 8 channels instead of 4 x 4).  Arithmetic: the bf16 values are widened exactly (<< 16) and
+// go through the same fp32 chain in the same order => the same bits as the 4-lane kernel and the oracle on the rounded maps.
+// Lane -> voxel for P1 as in the fp32 brick kernel (lane = lx*16 + ly*4 + lz); gather slot i of lane pair g32 = lane/2 is
+// voxel 32*i + g32.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 r, float (&f)[8])
+{
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ void pipe_views_h(const Views &hm, const float *__restrict__ cam, const Geom &g, int bs, float x,
+                                             float y, float z, bool inb, float *ws, int lane, float (&acc)[2][8],
+                                             uint32_t &mymask)
+{
+    constexpr int JP = 16;
+    int *wsi = reinterpret_cast<int *>(ws);
+    float4 *ws4 = reinterpret_cast<float4 *>(ws);
+    const unsigned long long inbm = __builtin_amdgcn_ballot_w64(inb);
+    auto P1 = [&](int c) -> bool {
+        const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
+        P1State st;
+        const bool go = project_pk(cm, g, x, y, z, inbm, st);
+        add_mask(mymask, st.bm);
+        if (st.nm != 0ull && lane_of(st.nm)) mymask |= 0x80000000u;
+        if (!go) return false;
+        const unsigned long long um = st.bm & ~st.nm;
+        if (um == 0ull) return false;
+        const RecPk r = make_record_pk(lane_of(um), st.i, g.w, g.h);
+        const int v = (c & 1) * 64 + lane;
+        wsi[WOFF + v] = (int)__umul24((unsigned)(JP * 2), __umul24((unsigned)r.y0, (unsigned)g.w) + (unsigned)r.x0);     // bytes
+        ws4[v] = make_float4(r.wt.x, r.wt.y, r.wb.x, r.wb.y);
+        return true;
+    };
+    const int g32 = lane >> 1, q = lane & 1;
+    const uint32_t qoff = 16u * (uint32_t)q;                    // this lane's 8 channels, bytes
+    const size_t row_bytes = (size_t)g.w * JP * 2;
+    bool have = P1(0);
+#pragma unroll 1
+    for (int c = 0; c < g.V; ++c) {
+        const bool cur = have;
+        const char *vb = reinterpret_cast<const char *>(hm.p[c]) + (size_t)bs * g.h * row_bytes;
+        const char *vb2 = vb + row_bytes;
+        const int rb = (c & 1) * 64 + g32;
+        if (cur) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint4 t00[2], t10[2], t01[2], t11[2];
+        if (cur) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t off = (uint32_t)wsi[WOFF + rb + 32 * i] + qoff;
+                t11[i] = *reinterpret_cast<const uint4 *>(vb2 + off + JP * 2);
+                t01[i] = *reinterpret_cast<const uint4 *>(vb2 + off);
+                t10[i] = *reinterpret_cast<const uint4 *>(vb + off + JP * 2);
+                t00[i] = *reinterpret_cast<const uint4 *>(vb + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 wq = ws4[rb + 32 * i];                 // (w00, w10, w01, w11)
+                float a[8], b[8], cc[8], d[8];
+                bf16x8_to_f32(t00[i], a); bf16x8_to_f32(t10[i], b); bf16x8_to_f32(t01[i], cc); bf16x8_to_f32(t11[i], d);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    // ATen's bilinear chain per channel: fma(se, wse, fma(sw, wsw, fma(ne, wne, nw * wnw)))
+                    v2f v = v2f{a[k], a[k + 1]} * pk2(wq.x);
+                    v = pk_fma(v2f{b[k], b[k + 1]}, pk2(wq.y), v);
+                    v = pk_fma(v2f{cc[k], cc[k + 1]}, pk2(wq.z), v);
+                    v = pk_fma(v2f{d[k], d[k + 1]}, pk2(wq.w), v);
+                    const v2f s2 = v2f{acc[i][k], acc[i][k + 1]} + v;
+                    acc[i][k] = s2.x; acc[i][k + 1] = s2.y;
+                }
+            }
+        }
+    }
+}
+
+template <bool OUTCL, typename TO>
+__global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_h_kernel(Views hm, const float *__restrict__ cam,
+                                                                  const float *__restrict__ centers,
+                                                                  const uint8_t *__restrict__ valid,
+                                                                  float *__restrict__ cubes, float *__restrict__ grids,
+                                                                  Geom g, int wgs_per_sample, int nby, int nzc, int zw)
+{
+    constexpr int JP = 16;
+    constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
+    extern __shared__ __attribute__((aligned(16))) float bsmem[];
+    int b, wg;
+    if (!xcd_map_fast(blockIdx.x, g, b, wg)) return;
+    int zc, t;
+    if (!(g.xcd_order & 2)) udiv_magic((uint32_t)wg, (uint32_t)g.bk_nxy, g.bk_magic_nxy, zc, t);
+    else { zc = wg % nzc; t = wg / nzc; }
+    int bx, by;
+    udiv_magic((uint32_t)t, (uint32_t)g.bk_nby, g.bk_magic_nby, bx, by);
+    const int bs = g.sample_of ? g.sample_of[b] : b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = bx * BR, y0 = by * BR, zbase = zc * zw * BR, z0 = zbase + wave * BR;
+    TO *cb = reinterpret_cast<TO *>(cubes) + (OUTCL ? (size_t)b * g.J * g.N : (size_t)b * g.sB);
+    float *ws = bsmem + wave * WLDS;
+
+    // P1 mapping: this lane's voxel
+    const int lx = lane >> 4, ly = (lane >> 2) & 3, lz = lane & 3;
+    const int vx = x0 + lx, vy = y0 + ly, vz = z0 + lz;
+    const bool inb = vx < g.X && vy < g.Y && vz < g.Z;
+    const int n = (min(vx, g.X - 1) * g.Y + min(vy, g.Y - 1)) * g.Z + min(vz, g.Z - 1);
+    const int g32 = lane >> 1, q = lane & 1;
+
+    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+        if (inb) {
+            const size_t zo = (size_t)vx * g.sX + (size_t)vy * g.sY + vz;
+            for (int j = 0; j < g.J; ++j)
+                Store4<TO>::store1(cb + (OUTCL ? ((size_t)n * g.J + j) : ((size_t)j * g.sJ + zo)), 0.0f);
+            if (grids) {
+                float *gp = grids + ((size_t)b * g.N + n) * 3;
+                gp[0] = 0.0f; gp[1] = 0.0f; gp[2] = 0.0f;
+            }
+            if (g.pass_mask) g.pass_mask[(size_t)b * g.N + n] = 0;
+        }
+        return;
+    }
+
+    if (z0 < g.Z) {
+        const float x = linspace_step(g.Lx, g.stepx, g.X, min(vx, g.X - 1)) + centers[3 * b + 0];
+        const float y = linspace_step(g.Ly, g.stepy, g.Y, min(vy, g.Y - 1)) + centers[3 * b + 1];
+        const float z = linspace_step(g.Lz, g.stepz, g.Z, min(vz, g.Z - 1)) + centers[3 * b + 2];
+        if (grids && inb) {
+            float *gp = grids + ((size_t)b * g.N + n) * 3;
+            gp[0] = x; gp[1] = y; gp[2] = z;
+        }
+        uint32_t mymask = 0;
+        float acc[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[i][k] = 0.0f;
+        pipe_views_h(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask);
+
+        __builtin_amdgcn_wave_barrier();
+        const float den_l = (float)(mymask & 0x7fffffffu) + 1e-6f;
+        const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = 32 * i + g32;                             // this slot's voxel inside the brick
+            const float den = __shfl(den_l, v);
+            const float rden = __shfl(rden_l, v);
+            const bool bad = rden == 0.0f;
+            const int gx = x0 + (v >> 4), gy = y0 + ((v >> 2) & 3), gz = z0 + (v & 3);
+            const bool vin = gx < g.X && gy < g.Y && gz < g.Z;
+            const int gn = (min(gx, g.X - 1) * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = fuse_rcp(acc[i][k], den, rden);
+            if (g.pass_mask) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float pre = fuse_pre(acc[i][k], den, rden);
+                    if (!bad && pre >= 0.0f && pre <= 1.0f) bits |= 1u << (8 * q + k);
+                }
+                bits |= (uint32_t)__shfl_xor((int)bits, 1);
+                if (q == 0 && vin) g.pass_mask[(size_t)b * g.N + gn] = (uint16_t)bits;
+            }
+            if (OUTCL) {
+                if (vin) {
+                    TO *dst = cb + (size_t)gn * g.J + 8 * q;
+                    if (8 * q < g.J) Store4<TO>::store_nt(dst, make_float4(o[0], o[1], o[2], o[3]));
+                    if (8 * q + 4 < g.J) Store4<TO>::store_nt(dst + 4, make_float4(o[4], o[5], o[6], o[7]));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ws[(8 * q + k) * WOSTR + v] = o[k];
+            }
+        }
+    }
+    if (OUTCL) return;
+    __syncthreads();
+    // workgroup store of the (J, 4, 4, 4*zw) block: thread -> (channel phase jj, column, brick of the stack); the LDS tile
+    // is indexed by the voxel's brick-local number lx*16 + ly*4 + lz, as the fp32 kernel's (slot*16 + g16)
+    const float rzw = 1.0f / (float)zw;
+    const int per = 16 * zw;
+    const int jj = (int)(((float)(tid >> 4) + 0.5f) * rzw);
+    const int cw = tid - jj * per;
+    const int col = (int)(((float)cw + 0.5f) * rzw), wz = cw - col * zw;
+    const int sx = x0 + (col >> 2), sy = y0 + (col & 3), sz = zbase + wz * BR;
+    if (sx >= g.X || sy >= g.Y || sz >= g.Z) return;
+    const float *tile = bsmem + wz * WLDS + col * 4;
+    TO *dst = cb + (size_t)sx * g.sX + (size_t)sy * g.sY + sz;
+    if (g.vec4 && (g.Z & 3) == 0) {
+        for (int j = jj; j < g.J; j += 4) {
+            const float4 o = *reinterpret_cast<const float4 *>(tile + j * WOSTR);
+            Store4<TO>::store_nt(dst + (size_t)j * g.sJ, o);
+        }
+    } else {
+        const int nz = min(BR, g.Z - sz);
+        for (int j = jj; j < g.J; j += 4)
+            for (int k = 0; k < nz; ++k) Store4<TO>::store1(dst + (size_t)j * g.sJ + k, tile[j * WOSTR + k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: lane = voxel, planar layout.  Pass 1 recomputes the pre-clamp forward value (the
 // clamp mask: grad flows where 0 <= pre <= 1, torch.clamp backward), pass 2 scatters.
 // ------------------------------------------------------------------------------------------
@@ -1141,6 +1356,15 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
 #define SP3D_BRICK(CL_, TI_, TO_) \
     hipLaunchKernelGGL((unproject_brick_kernel<JP, CL_, TI_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
+        if ((io & 1) && JP == 16 && !((variant >> 9) & 1)) {
+            // bf16 heat-maps: two lanes per pixel (tuning bit 9: keep the four-lane kernel below, for A/B)
+#define SP3D_BRICK_H(CL_, TO_) \
+    hipLaunchKernelGGL((unproject_brick_h_kernel<CL_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
+            if (io & 2) { if (out_cl) SP3D_BRICK_H(true, bf16_t); else SP3D_BRICK_H(false, bf16_t); }
+            else { if (out_cl) SP3D_BRICK_H(true, float); else SP3D_BRICK_H(false, float); }
+#undef SP3D_BRICK_H
+            return SP3D_OK;
+        }
         if (io != 0) {
             if constexpr (JP == 16) {
                 switch ((io & 3) * 2 + (out_cl ? 1 : 0)) {

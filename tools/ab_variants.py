@@ -92,6 +92,8 @@ def main():
                                                          cube, gs, img, False)
         fns["nhwc_bf16_io"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
                                                          cube, gs, img, False, out_dtype=torch.bfloat16)
+        fns["nhwc_bf16_io_chlast"] = lambda: _lib.unproject_fwd(views16, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w,
+                                                                cube, gs, img, False, channels_last=True, out_dtype=torch.bfloat16)
         fns["pack_bf16"] = lambda: _lib.pack_heatmaps(hms, jp=16, out=packed16)
         times = {k: [] for k in fns}
         ref_out = None
@@ -109,7 +111,8 @@ def main():
                 times[k].append(timed(fn, args.iters if k != "planar" else max(5, args.iters // 10)))
         alg = 4.0 * B * (V * J * h * w + J * N)
         # 2 bytes per element for tensors stored as bf16
-        alg_by = {"nhwc_bf16_in": B * (2.0 * V * J * h * w + 4.0 * J * N), "nhwc_bf16_io": 2.0 * B * (V * J * h * w + J * N)}
+        alg_by = {"nhwc_bf16_in": B * (2.0 * V * J * h * w + 4.0 * J * N), "nhwc_bf16_io": 2.0 * B * (V * J * h * w + J * N),
+                  "nhwc_bf16_io_chlast": 2.0 * B * (V * J * h * w + J * N)}
         report[name] = {"algorithmic_MB": round(alg / 1e6, 2),
                         "algorithmic_MB_bf16_in": round(alg_by["nhwc_bf16_in"] / 1e6, 2),
                         "algorithmic_MB_bf16_io": round(alg_by["nhwc_bf16_io"] / 1e6, 2)}
