@@ -482,10 +482,13 @@ def unprojection_grids_leg(dev, iters=100):
         if c["bf16"]:
             packed = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
             views = [packed[i] for i in range(V)]
-            fn = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img, False,
-                                            out_dtype=torch.bfloat16)
+            fn = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
+                                            channels_last=True, out_dtype=torch.bfloat16)
+            fn_planar = lambda: _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w, cube, gs, img,
+                                                   False, out_dtype=torch.bfloat16)
             alg = 2.0 * B * (V * J * h * w + J * N)
-            what = "bf16 heat-maps and cubes, fp32 arithmetic, planar result"
+            what = ("bf16 heat-maps and cubes, fp32 arithmetic, channels-last result (as the fp32 rows); two lanes per 32-byte "
+                    "pixel (unproject_brick_h_kernel)")
         else:
             packed = _lib.pack_heatmaps(hms, jp=16)
             views = [packed[i] for i in range(V)]
@@ -500,6 +503,9 @@ def unprojection_grids_leg(dev, iters=100):
         out[name] = {"kernel_us": round(t * 1e3, 2), "algorithmic_bytes": int(alg),
                      "achieved_GBps": round(alg / (t * 1e-3) / 1e9, 1), "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "what": what}
+        if c["bf16"]:
+            event_time_ms(fn_planar, 100, dev)
+            out[name]["kernel_us_planar_result"] = round(float(np.median([event_time_ms(fn_planar, iters, dev) for _ in range(3)])) * 1e3, 2)
         del packed, views, hms
     try:
         out["output_check"] = unprojection_grids_check(dev)
