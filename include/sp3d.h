@@ -358,26 +358,6 @@ int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const floa
 int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode, int B,
                      int X, int Y, int Z, int C, int O, void *stream);
 
-/* The same with split ("S3") activations between consecutive layers.  An S3 tensor of an (X,Y,Z) volume is ZERO-BORDERED and
- * padded to whole blocks, 8-channel chunk slowest: (B, C/8, PX, PY, PZ, 2, 8 dwords) with (PX,PY,PZ) = sp3d_conv3_s3_dims(X,Y,Z)
- * = (16 ceil(X/16) + 2, 8 ceil(Y/8) + 2, 4 ceil(Z/4) + 2); volume voxel (x,y,z) lives at (x+1, y+1, z+1), and per voxel and
- * 4-channel group (channel = 8 chunk + 4 group + q) it holds the two A operands [lo hi | hi mid] (bf16 pairs) of the three
- * exact pieces of each fp32 value.  The CALLER zeroes the
- * tensor once; the kernels only ever write volume voxels, so the border stays zero across calls.
- * xs != NULL (C = 32): the input is read pre-split (x may be NULL) - the loader waves then move it with
- * global_load_lds_dwordx4, no bounds tests, no VALU; ys != NULL (modes 1, 2): the result is ALSO (y != NULL) or ONLY
- * (y == NULL) written as an S3 tensor for the next layer.  16-byte aligned. */
-int sp3d_conv3_s3_dims(int X, int Y, int Z, int *padded3);
-
-/* Batched product of the three-launch Winograd form (sp3d_wino_input -> this -> sp3d_wino_output; replaces the fp32 library
- * GEMM between them): M[p] (T,O) = V[p] (T,C) . U[p] (C,O) for p < P, fp32 in and out, computed on the bf16 matrix pipe as
- * exact three-piece splits of both operands (six partial products per multiply, fp32 accumulation).  W3: U as 48-byte
- * records {hi,lo} {hi,hi} {mid,mid} at index ((p*(C/8) + chunk)*2 + half)*O + o (_lib.wino_gemm_weights_split), 16-byte
- * aligned.  (C,O) in {(64,128),(128,128)}: the quarter-resolution Res3DBlocks of v2v_net.py:72-110. */
-int sp3d_wino_gemm_split(const float *V, const void *W3, float *M, int P, int T, int C, int O, void *stream);
-int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
-                        const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream);
-
 /*
  * Scatter + epilogue of ConvTranspose3d(kernel 2, stride 2) -> BatchNorm -> ReLU (+ skip) (lib/models/v2v_net.py:57-69,
  * 100-108) once the layer has been computed as one GEMM G (batch*X*Y*Z, 8*O) with column order (i,j,k,o):

@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_conv3_split_ex", "sp3d_conv3_s3_dims", "sp3d_wino_gemm_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -622,97 +622,32 @@ def conv_weights_split(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo, hi, hi, mid, mid], -2).contiguous()        # the B operands {bh,bl} {bh,bh} {bm,bm}
 
 
-def conv3_s3_dims(X: int, Y: int, Z: int):
-    """padded extents (PX, PY, PZ) of the zero-bordered split tensor of an (X,Y,Z) volume (include/sp3d.h)"""
-    lib = load()
-    out = (C.c_int * 3)()
-    check(lib.sp3d_conv3_s3_dims(int(X), int(Y), int(Z), out), "sp3d_conv3_s3_dims")
-    return int(out[0]), int(out[1]), int(out[2])
-
-
-def conv3_s3_empty(B: int, X: int, Y: int, Z: int, channels: int, device) -> torch.Tensor:
-    """a zeroed S3 tensor (B,channels/8,PX,PY,PZ,2,8) int32 for an (X,Y,Z) volume; the kernels keep its border zero, so it
-    can be handed to conv3_split_(out_s3=...) again and again"""
-    PX, PY, PZ = conv3_s3_dims(X, Y, Z)
-    return torch.zeros((B, channels // 8, PX, PY, PZ, 2, 8), dtype=torch.int32, device=device)
-
-
-def conv3_split_(x: Optional[torch.Tensor], W3: torch.Tensor, shift: torch.Tensor, mode: int,
-                 residual: Optional[torch.Tensor] = None, x_s3: Optional[torch.Tensor] = None, want_f32: bool = True,
-                 want_s3: bool = False, dims=None, out_s3: Optional[torch.Tensor] = None):
+def conv3_split_(x: torch.Tensor, W3: torch.Tensor, shift: torch.Tensor, mode: int,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3x3 stride-1 'same' conv of channels_last_3d x with the fused epilogue, direct (implicit GEMM) on the bf16 matrix
-    pipe with exact three-piece splits; W3 = conv_weights_split(w).  x_s3: the input as a zero-bordered S3 tensor
-    (B,C/8,PX,PY,PZ,2,8) int32 written by the previous layer (x may then be None; dims = (X,Y,Z) of the volume, taken from
-    x / residual when given); want_s3: also return the result as an S3 tensor (out_s3: write it there - a tensor from
-    conv3_s3_empty - instead of a new zeroed one).  Returns y, or (y | None, y_s3) when want_s3."""
+    pipe with exact three-piece splits; W3 = conv_weights_split(w).  Returns the channels_last_3d result (B,O,X,Y,Z).
+    (Round 3's chained form - split activations handed from layer to layer - measured no gain and was removed in round 4.)"""
     lib = load()
-    src = x if x is not None else x_s3
-    _require_cuda(src, "x")
-    if x is not None:
-        B, Cc, X, Y, Z = (int(v) for v in x.shape)
-        if x_s3 is None and (not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32):
-            raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
-    elif residual is not None:
-        B, _, X, Y, Z = (int(v) for v in residual.shape)
-    elif dims is not None:
-        B = int(x_s3.shape[0])
-        X, Y, Z = (int(v) for v in dims)
-    else:
-        raise Sp3dError("conv3_split_: dims=(X,Y,Z) needed with a split input and no x / residual")
-    if x_s3 is not None:
-        Cc = 8 * int(x_s3.shape[1])
-        if x_s3.dtype != torch.int32 or not x_s3.is_contiguous() or \
-                tuple(x_s3.shape) != (B, Cc // 8) + conv3_s3_dims(X, Y, Z) + (2, 8):
-            raise Sp3dError("conv3_split_: x_s3 must be a dense int32 (B,C/8,PX,PY,PZ,2,8) tensor (conv3_s3_dims)")
+    _require_cuda(x, "x")
+    B, Cc, X, Y, Z = (int(v) for v in x.shape)
+    if not x.is_contiguous(memory_format=torch.channels_last_3d) or x.dtype != torch.float32:
+        raise Sp3dError("conv3_split_: float32 channels_last_3d activations expected")
     O = int(W3.shape[3])
-    dev = src.device
-    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3) if want_f32 else None
-    ys = None
-    if want_s3:
-        ys = out_s3 if out_s3 is not None else conv3_s3_empty(B, X, Y, Z, O, dev)
-        if ys.dtype != torch.int32 or not ys.is_contiguous() or tuple(ys.shape) != (B, O // 8) + conv3_s3_dims(X, Y, Z) + (2, 8):
-            raise Sp3dError("conv3_split_: out_s3 must be a dense int32 (B,O/8,PX,PY,PZ,2,8) tensor (conv3_s3_empty)")
+    dev = x.device
+    y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
     if residual is not None and (tuple(residual.shape) != (B, O, X, Y, Z) or
                                  not residual.is_contiguous(memory_format=torch.channels_last_3d)):
         residual = residual.contiguous(memory_format=torch.channels_last_3d)
-    lib.sp3d_conv3_split_ex.restype = C.c_int
-    lib.sp3d_conv3_split_ex.argtypes = [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]
-    check(lib.sp3d_conv3_split_ex(x.data_ptr() if (x is not None and x_s3 is None) else None,
-                                  x_s3.data_ptr() if x_s3 is not None else None, W3.data_ptr(),
-                                  y.data_ptr() if y is not None else None, ys.data_ptr() if ys is not None else None,
-                                  shift.data_ptr(), residual.data_ptr() if residual is not None else None, int(mode),
-                                  B, X, Y, Z, Cc, O, _stream(dev)), "sp3d_conv3_split_ex")
-    return (y, ys) if want_s3 else y
-
-
-def wino_gemm_weights_split(U: torch.Tensor) -> torch.Tensor:
-    """U (64,C,O) fp32 -> the operand records sp3d_wino_gemm_split reads: (64, C/8, 2, O, 6, 4) bfloat16 = the three B operands
-    {hi,lo} {hi,hi} {mid,mid} of 4 channels each (conv_weights_split's records with the Winograd point in the tap's place)"""
-    pc = wino_weights_split(U, 8)                                          # [p, chunk, half, o, piece (mid,hi,lo), 4]
-    mid, hi, lo = pc[..., 0, :], pc[..., 1, :], pc[..., 2, :]
-    return torch.stack([hi, lo, hi, hi, mid, mid], -2).contiguous()
-
-
-def wino_gemm_split(V: torch.Tensor, W3: torch.Tensor) -> torch.Tensor:
-    """M[p] = V[p] @ U[p] for the 64 Winograd points (V (64,T,C) fp32, W3 = wino_gemm_weights_split(U), O = 128) on the bf16
-    matrix pipe with exact three-piece splits; returns M (64,T,O) fp32"""
-    lib = load()
-    _require_cuda(V, "V")
-    P, T, Cc = (int(v) for v in V.shape)
-    O = int(W3.shape[3])
-    if V.dtype != torch.float32 or not V.is_contiguous() or W3.dtype != torch.bfloat16 or not W3.is_contiguous() or \
-            tuple(W3.shape) != (P, Cc // 8, 2, O, 6, 4):
-        raise Sp3dError("wino_gemm_split: V (P,T,C) float32 dense and W3 = wino_gemm_weights_split(U) expected")
-    M = torch.empty((P, T, O), dtype=torch.float32, device=V.device)
-    lib.sp3d_wino_gemm_split.restype = C.c_int
-    lib.sp3d_wino_gemm_split.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
-    check(lib.sp3d_wino_gemm_split(V.data_ptr(), W3.data_ptr(), M.data_ptr(), P, T, Cc, O, _stream(V.device)),
-          "sp3d_wino_gemm_split")
-    return M
+    lib.sp3d_conv3_split.restype = C.c_int
+    lib.sp3d_conv3_split.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
+    check(lib.sp3d_conv3_split(x.data_ptr(), W3.data_ptr(), y.data_ptr(), shift.data_ptr(),
+                               residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
+                               _stream(dev)), "sp3d_conv3_split")
+    return y
 
 
 def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
-                 residual: Optional[torch.Tensor] = None, W3: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3x3 stride-1 'same' conv of channels-last x (B,C,X,Y,Z as torch.channels_last_3d) with pre-transformed weights
     U (64,C,O), fused with the layer epilogue; returns a channels_last_3d tensor (B,O,X,Y,Z)."""
     lib = load()
@@ -724,8 +659,7 @@ def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: in
     T = B * ((X + 1) // 2) * ((Y + 1) // 2) * ((Z + 1) // 2)
     V = torch.empty((64, T, Cc), dtype=torch.float32, device=x.device)
     check(lib.sp3d_wino_input(x.data_ptr(), V.data_ptr(), B, X, Y, Z, Cc, _stream(x.device)), "sp3d_wino_input")
-    # W3 (wino_gemm_weights_split(U), O = 128): the 64 products as exact bf16 splits on the bf16 matrix pipe, else the library's fp32 GEMM
-    M = wino_gemm_split(V, W3) if W3 is not None else torch.bmm(V, U)
+    M = torch.bmm(V, U)         # the 64 products: the library's fp32 batched GEMM (an own split-bf16 GEMM was not faster: round 3)
     y = torch.empty((B, X, Y, Z, O), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
         residual = residual.contiguous(memory_format=torch.channels_last_3d)

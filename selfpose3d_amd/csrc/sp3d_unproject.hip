@@ -23,7 +23,6 @@
 #include <string.h>
 #include "sp3d_device.h"
 #include "sp3d_proj_pk.h"
-#include "sp3d_unproject_patch.h"
 
 namespace sp3d {
 
@@ -1465,12 +1464,7 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     if (out_cl && (g.J & 3)) return SP3D_EUNSUPPORTED;           // channels-last rows must be 16-B multiples
     if (g.w < 2 || g.h < 2) variant &= ~(8 | 32);                // the clamped 2x2 block needs a 2x2 image
     if ((int64_t)g.h * g.w > (1 << 24)) variant &= ~(8 | 32);    // the pipelined kernels form pixel indices with 24-bit multiplies
-    if ((variant & 128) && out_cl && Jp == 16 && g.w >= 2 && g.h >= 2 && (int64_t)g.h * g.w <= (1 << 24) && g.w < 65536 && g.h < 65536) {
-        // wave-private LDS-staged patches (dense grids, channels-last result): sp3d_unproject_patch.hip
-        const int rc = launch_patch(v, Jp, cam, centers, valid, cubes, grids, g, out_cl, io, s);
-        return rc ? rc : launch_status();
-    }
-    variant &= ~128;
+    variant &= ~128;                                             // (round-3 LDS patch kernels: measured slower, removed in round 4)
     if (variant & 32) variant |= 8;
     if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
     if (io) variant |= 16;

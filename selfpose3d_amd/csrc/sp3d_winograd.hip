@@ -889,40 +889,11 @@ constexpr int CD_BUF = 2 * CD_PLANE;                                   // 17 328
 constexpr int CD_NV4 = CD_RX * CD_RY * CD_RZ * 2;                      // float4 per item: 2 160
 constexpr int CD_PROD = 4;                                             // producer waves: one per SIMD
 constexpr int CD_PER = (CD_NV4 + 64 * CD_PROD - 1) / (64 * CD_PROD);   // 9 float4 per producer lane
-// split ("S3") input: the staged buffer is a linear array of 16-byte slots (2 per voxel and 4-channel group, + 1 of padding
-// per z plane); one global_load_lds_dwordx4 fills 64 consecutive slots, 68 of them fill a buffer (the last one runs 20 slots
-// past CD_BUF, hence the buffer stride below)
-constexpr int CD_NSLOT = CD_BUF / 4;                                   // 4 332
-constexpr int CD_NDMA = (CD_NSLOT + 63) / 64;                          // 68
-constexpr int CD_DMA_PER = CD_NDMA / CD_PROD;                          // 17 per loader wave
-static_assert(CD_NDMA % CD_PROD == 0, "DMA instructions must divide over the loader waves");
-constexpr int CD_BUFS = CD_NDMA * 256;                                 // buffer stride in dwords: 17 408 = 69 632 B
-// zero-bordered S3 tensor of an (X,Y,Z) volume: (B, C/8, PX, PY, PZ, 2, 8 dwords), whole blocks + 1 voxel of zeros all round
-__host__ __device__ constexpr int cd_pad(int n, int blk) { return (n + blk - 1) / blk * blk + 2; }
-
-// Pause (x 64 cycles) after every DMA instruction of a loader wave: 17 back-to-back DMA instructions sit in the CU's
-// texture-address queue in front of the consumers' weight loads (prefetched one step = ~1 100 cycles ahead), and the matrix
-// stream then waits for its weights - tap loop 14.0 k cycles per item unthrottled, 12.5 k with 4, 12.3 k with 8 (but then
-// the DMA (13 k) is longer than the item); tools/conv3_timeline.py --s3 --var=sl2|sl4|sl8.
+// buffer stride in dwords (17 408 = 69 632 B: the LDS layout the bank-conflict search was done for; CD_BUF rounded up to 68 x 256)
+constexpr int CD_BUFS = ((CD_BUF / 4 + 63) / 64) * 256;
 #ifndef SP3D_WG_ABLATE
 #define SP3D_WG_ABLATE 0
 #endif
-#ifndef SP3D_CD_DMA_SLEEP
-#define SP3D_CD_DMA_SLEEP 4
-#endif
-#ifndef SP3D_CD_DMA_POLICY
-#define SP3D_CD_DMA_POLICY ""
-#endif
-// 16 bytes per lane from gbase + voff straight into LDS at lds_dst + 16 * lane (no VGPR round trip, no ds_write)
-__device__ __forceinline__ void cd_lds_dma16(uint32_t voff, uint32_t lds_dst, const char *gbase)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" SP3D_CD_DMA_POLICY "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_dst), "s"(gbase)
-                 : "memory");
-}
-
 struct CdRec { u32x4 hl, hh, mm; };                                    // weight record: B operands {bh,bl} {bh,bh} {bm,bm}
 
 
@@ -956,24 +927,16 @@ __device__ __forceinline__ void split3(const float4 a, u32x4 &q0, u32x4 &q1)
     q1 = u32x4{hi01, hi23, mid01, mid23};
 }
 
-// IN_S3: the input arrives already split ("S3" tensor (B,X,Y,Z,C/4,8 dwords): per voxel and 4-channel group the two A
-// operands [lo hi | hi mid], written by the previous layer's epilogue) - the producers then only copy, 4 instructions per
-// 32 bytes.  They get ONE issue slot per consumer matrix instruction (a co-resident wave's VALU only issues between the
-// matrix instructions: measured 58 cycles per producer instruction), so splitting in the producers (216 VALU per item)
-// made them the pole: 17 k cycles per item against the consumers' 12 k.
-// OUT: 1 fp32 channels-last result, 2 split result (S3) for the next layer, 3 both.
-template <int C, int MODE, bool IN_S3, int OUT>
+template <int C, int MODE>
 __global__ __launch_bounds__(64 * (4 + CD_PROD)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict__ W3, float *__restrict__ y,
                         const float *__restrict__ shift, const float *__restrict__ res, int B, int X, int Y, int Z, int NBX,
-                        int NBY, int NBZ, int nblocks, const unsigned *__restrict__ xs, unsigned *__restrict__ ys)
+                        int NBY, int NBZ, int nblocks)
 {
     constexpr int O = 32, NCH = C / 8;
     // operand roles: a split result wants (voxel, 4 consecutive channels) per lane = weights as the A operand (rows), an
     // fp32-only result wants (channel, 16 voxels) per lane = full 128-byte rows per store instruction (the transposed form's
     // 32-byte pieces cost 8-10 k cycles per block against 3-6 k)
-    constexpr bool SWAP = (OUT & 2) != 0;
-    const int PX = NBX * CD_BX + 2, PY = NBY * CD_BY + 2, PZ = NBZ * CD_BZ + 2;       // S3 tensors: zero-bordered, whole blocks
     extern __shared__ __attribute__((aligned(16))) unsigned cd_lds[];      // 2 x CD_BUFS dwords + 4 x 1024 floats of scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
     const int my_blocks = ((int)blockIdx.x < nblocks) ? (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -990,55 +953,6 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     if (wave >= 4) {
         // ---------------- producers: item k -> buffer k & 1 ----------------
         const int pt = tid - 256;                                          // 0 .. 64*CD_PROD-1
-        if (IN_S3) {
-            // split input (written by the previous layer's epilogue into a zero-bordered tensor): no bounds, no VALU, no
-            // ds_write - 17 global_load_lds_dwordx4 per wave and item.  Slot s of the buffer is (4-channel group, vz, vy, vx,
-            // half record); its offset from the region's first voxel does not depend on the item.  (With VGPR copies the
-            // loaders' ~50 instructions and bounds tests per item cost the consumers 2.3 k of their 11.7 k cycles: a
-            // co-resident wave's instruction delays the matrix stream by ~20 cycles, tools/conv3_timeline.py.)
-            const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;
-            uint32_t voff[CD_DMA_PER];
-#pragma unroll
-            for (int u = 0; u < CD_DMA_PER; ++u) {
-                const int sl = (pw * CD_DMA_PER + u) * 64 + lane;
-                const int plane = sl / (CD_PLANE / 4), r = sl % (CD_PLANE / 4);
-                const int vz = r / (CD_ZP / 4), r2 = r % (CD_ZP / 4);
-                const int vy = r2 / (CD_RX * 2), r3 = r2 % (CD_RX * 2);
-                const bool real = sl < CD_NSLOT && r2 < CD_RY * CD_RX * 2;            // else: padding slot, reads offset 0
-                voff[u] = real ? (uint32_t)((((r3 >> 1) * PY + vy) * PZ + vz) * 64 + plane * 32 + (r3 & 1) * 16) : 0u;
-            }
-            const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)cd_lds) + (uint32_t)pw * CD_DMA_PER * 1024u;
-            for (int k = 0; k <= n_items; ++k) {
-                if (k < n_items) {
-                    { const int item = k; CD_STAMP(0); }
-                    int b, ox0, oy0, oz0;
-                    decode(k, b, ox0, oy0, oz0);
-                    // region voxel (0,0,0) = volume voxel (ox0-1, ..) = padded voxel (ox0, oy0, oz0)
-                    // (chunk-major tensor: the 64 bytes of a voxel's 8-channel chunk, then z - a region row is 384 contiguous bytes)
-#ifdef SP3D_CD_DMA_SAME
-                    ox0 = 16; oy0 = 8; oz0 = 4; b = 0;                     // measurement build: every item reads one hot region
-#endif
-                    const int64_t pv0 = ((((int64_t)b * NCH + k % NCH) * PX + ox0) * PY + oy0) * PZ + oz0;
-                    const char *gb = reinterpret_cast<const char *>(xs) + pv0 * 64;
-                    const uint64_t gu = (uint64_t)(size_t)gb;
-                    const uint32_t glo = __builtin_amdgcn_readfirstlane((uint32_t)gu), ghi = __builtin_amdgcn_readfirstlane((uint32_t)(gu >> 32));
-                    const char *gbs = reinterpret_cast<const char *>((size_t)(((uint64_t)ghi << 32) | glo));
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(k & 1) * (CD_BUFS * 4u));
-#pragma unroll
-                    for (int u = 0; u < CD_DMA_PER; ++u) {
-                        cd_lds_dma16(voff[u], dst + (uint32_t)u * 1024u, gbs);
-#if SP3D_CD_DMA_SLEEP
-                        __builtin_amdgcn_s_sleep(SP3D_CD_DMA_SLEEP);
-#endif
-                    }
-                    { const int item = k; CD_STAMP(1); }
-                    __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0): the DMA data is in LDS
-                    { const int item = k; CD_STAMP(2); }
-                }
-                __syncthreads();
-            }
-            return;
-        }
         // fp32 input.  VALU issue on a SIMD goes to the older wave first: without priority the (younger) producers got the
         // slots the consumer's matrix stream left over - 28 cycles per instruction, 14 k cycles per item against the
         // consumers' 12 k
@@ -1160,11 +1074,11 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].hl, a0.lh[i + dx], acc[i]) : mfma_bf16(a0.lh[i + dx], w0.d[dx].hl, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.lh[i + dx], w0.d[dx].hl, acc[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].hh, a0.hm[i + dx], acc[i]) : mfma_bf16(a0.hm[i + dx], w0.d[dx].hh, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].hh, acc[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = SWAP ? mfma_bf16(w0.d[dx].mm, a0.hm[i + dx], acc[i]) : mfma_bf16(a0.hm[i + dx], w0.d[dx].mm, acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(a0.hm[i + dx], w0.d[dx].mm, acc[i]);
             }
             // issue order: one load between matrix instructions (a wave blocked on LDS issue cannot issue its matrix
             // instructions either: tools/conv3_timeline.py)
@@ -1184,14 +1098,14 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
             w0 = w1;
         }
         CD_STAMP(1);
-        if (!SWAP && cc == NCH - 1) {
+        if (cc == NCH - 1) {
             // D of the 32x32 MFMA: lane (col = t, h) holds rows m = 8 (v >> 2) + (v & 3) + 4 h, v = 0..15, of every accumulator;
             // row m of accumulator i is voxel (x = 4 wave + i, y = m & 7, z = m >> 3).  Each accumulator goes through the wave's
             // 4 KB of LDS scratch [voxel][channel] and comes back as (voxel, 4 channels) per lane: shift, residual, ReLU,
             // the fp32 result as float4 (128 B per voxel over 8 lanes) and / or the split operands for the next layer
             int b, ox0, oy0, oz0;
             decode(item, b, ox0, oy0, oz0);
-            if (OUT == 1 && ox0 + CD_BX <= X && oy0 + CD_BY <= Y && oz0 + CD_BZ <= Z) {
+            if (ox0 + CD_BX <= X && oy0 + CD_BY <= Y && oz0 + CD_BZ <= Z) {
                 // fp32 result only, interior block: straight from the accumulators, lane (t, h) owns channel t of voxels
                 // (x = 4 wave + i, y = 4 h + (v & 3), z = v >> 2); 128-byte rows per store, no LDS round trip (3 k cycles
                 // against 6-9 k for the transposed form below)
@@ -1237,59 +1151,12 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
 #if SP3D_W16_ABLATE & 16
                         if (a.x == 123.456f)
 #endif
-                        {
-                            if (OUT & 1) *reinterpret_cast<float4 *>(y + vox * O + 4 * g) = a;
-                        }
+                        *reinterpret_cast<float4 *>(y + vox * O + 4 * g) = a;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            }
-        }
-        if (SWAP && cc == NCH - 1) {
-            // The weights are the A operand (rows = output channels) and the voxels the B operand (columns): lane (t, h)
-            // holds, of voxel (x = 4 wave + i, y = t & 7, z = t >> 3), the channels 8 k + 4 h + j in acc[i][4 k + j] - four
-            // consecutive channels per k, which is a float4 of the channels-last result and one record of the split
-            // result, straight from the accumulators (the transposed roles needed a trip through LDS: 6-9 k cycles a block)
-            int b, ox0, oy0, oz0;
-            decode(item, b, ox0, oy0, oz0);
-            const int yo = oy0 + (t & 7), zo = oz0 + (t >> 3);
-            float4 sh4[4];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) sh4[k4] = *reinterpret_cast<const float4 *>(shift + 8 * k4 + 4 * h);
-            const bool inyz = yo < Y && zo < Z;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xo = ox0 + 4 * wave + i;
-                if (inyz && xo < X) {
-                    const int64_t vox = (((int64_t)b * X + xo) * Y + yo) * Z + zo;
-                    const int64_t pvox = (((int64_t)b * (O / 8) * PX + xo + 1) * PY + yo + 1) * PZ + zo + 1;      // chunk 0
-                    const int64_t pchunk = (int64_t)PX * PY * PZ;
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        float4 a = make_float4(acc[i][4 * k4] + sh4[k4].x, acc[i][4 * k4 + 1] + sh4[k4].y,
-                                               acc[i][4 * k4 + 2] + sh4[k4].z, acc[i][4 * k4 + 3] + sh4[k4].w);
-                        float4 rr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (MODE >= 2) rr = *reinterpret_cast<const float4 *>(res + vox * O + 8 * k4 + 4 * h);
-                        if (MODE == 2) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
-                        if (MODE >= 1) { a.x = fmaxf(a.x, 0.0f); a.y = fmaxf(a.y, 0.0f); a.z = fmaxf(a.z, 0.0f); a.w = fmaxf(a.w, 0.0f); }
-                        if (MODE == 3) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
-#if SP3D_W16_ABLATE & 16
-                        if (a.x == 123.456f)
-#endif
-                        {
-                            if (OUT & 1) *reinterpret_cast<float4 *>(y + vox * O + 8 * k4 + 4 * h) = a;
-                            if (OUT & 2) {
-                                u32x4 q0, q1;
-                                split3(a, q0, q1);
-                                unsigned *p = ys + (pvox + k4 * pchunk) * 16 + h * 8;
-                                *reinterpret_cast<u32x4 *>(p) = q0;
-                                *reinterpret_cast<u32x4 *>(p + 4) = q1;
-                            }
-                        }
-                    }
-                }
             }
         }
         CD_STAMP(2);
@@ -1298,140 +1165,6 @@ void conv3_split_kernel(const float *__restrict__ x, const unsigned *__restrict_
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Batched GEMM of the three-launch Winograd form (quarter-resolution layers, C = 64 | 128 -> O = 128 on 20x20x5): per
-// Winograd point p, M[p] (T x O) = V[p] (T x C) . U[p] (C x O), on the bf16 matrix pipe with exact three-piece splits of both
-// operands (the six products of conv3_split_kernel, fp32 accumulation) instead of rocBLAS on v_mfma_f32_32x32x2_f32
-// (27.7 us per layer = 91 TFLOP/s on 64 x (1200 x 128 x 128)).  Workgroup = one point p, 4 waves = the 4 blocks of 32
-// outputs; a wave keeps ITS weights of every channel chunk in registers for the whole kernel (C/8 x 3 operands = 192 VGPRs at
-// C = 128: one wave per SIMD), the rows go through LDS 128 at a time: all threads load fp32 rows, split them once, and store
-// the two A operands [lo hi] / [hi mid] in separate planes (lane-consecutive 16-byte slots: conflict-free ds_read_b128).
-// W3: the records of conv_weights_split with the point in the place of the tap.
-// ------------------------------------------------------------------------------------------
-template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void wino_gemm_split_kernel(const float *__restrict__ V, const unsigned *__restrict__ W3, float *__restrict__ M, int T, int G)
-{
-    constexpr int C = 8 * NCH, F4 = C / 4, O = 128, ROWS = 128;
-    constexpr int QPLANE = 4 * NCH * 2 * 32;                          // u32x4 slots per operand plane
-    extern __shared__ __attribute__((aligned(16))) u32x4 wg_lds[];    // [q 2][row block 4][chunk NCH][half 2][row 32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = lane & 31, h = lane >> 5;
-    const int p = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
-    CdRec b[NCH];
-    {
-        const unsigned *wl = W3 + (((int64_t)p * NCH * 2 + h) * O + 32 * wave + t) * 12;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const unsigned *r = wl + (int64_t)c * 2 * O * 12;
-#if SP3D_WG_ABLATE & 64
-            (void)r; b[c].hl = u32x4{(unsigned)c, (unsigned)lane, 3u, 4u}; b[c].hh = b[c].hl ^ 5u; b[c].mm = b[c].hl ^ 9u;
-#else
-            b[c].hl = *reinterpret_cast<const u32x4 *>(r);
-            b[c].hh = *reinterpret_cast<const u32x4 *>(r + 4);
-            b[c].mm = *reinterpret_cast<const u32x4 *>(r + 8);
-#endif
-        }
-    }
-    const float *Vp = V + (int64_t)p * T * C;
-    float *Mp = M + (int64_t)p * T * O;
-    const int ntile = (T + ROWS - 1) / ROWS;
-    // staging map: thread -> (row r8 of 8, float4 f4 of the row): a wave reads 8 rows x 128 contiguous bytes, and its
-    // 8 row-consecutive lanes write 8 consecutive 16-byte slots
-    const int r8 = tid & 7, f4 = tid >> 3;
-    constexpr int SU = ROWS / 8;                                       // 16 passes of 8 rows
-    float4 d[SU];
-    auto fetch = [&](int at) {                                         // rows of tile `at`: in flight during the products
-        const int row0 = at * ROWS;
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            const int row = row0 + 8 * u + r8;
-            d[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#if SP3D_WG_ABLATE & 32
-            d[u].x = (float)row;
-#else
-            if (f4 < F4 && row < T) d[u] = *reinterpret_cast<const float4 *>(Vp + (int64_t)row * C + 4 * f4);
-#endif
-        }
-    };
-    if (g < ntile) fetch(g);
-    for (int at = g; at < ntile; at += G) {
-        const int row0 = at * ROWS;
-        __syncthreads();                                               // the previous tile's operands have been read
-        if (f4 < F4) {
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int lr = 8 * u + r8;
-                u32x4 q0, q1;
-#if SP3D_WG_ABLATE & 4
-                q0 = u32x4{__float_as_uint(d[u].x), __float_as_uint(d[u].y), __float_as_uint(d[u].z), __float_as_uint(d[u].w)}; q1 = q0 ^ 0x1u;
-#else
-                split3(d[u], q0, q1);
-#endif
-                const int idx = (((lr >> 5) * NCH + (f4 >> 1)) * 2 + (f4 & 1)) * 32 + (lr & 31);
-#if SP3D_WG_ABLATE & 16
-                if (q0.x == 0x12345u)
-#endif
-                {
-                wg_lds[idx] = q0;
-                wg_lds[QPLANE + idx] = q1;
-                }
-            }
-        }
-        __syncthreads();
-        if (at + G < ntile) fetch(at + G);
-        f32x16 acc[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
-        // consecutive matrix instructions are independent (4 row blocks), operands one chunk ahead
-        u32x4 a0[4], a1[4], n0[4], n1[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int idx = ((m * NCH) * 2 + h) * 32 + t;
-            a0[m] = wg_lds[idx]; a1[m] = wg_lds[QPLANE + idx];
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int idx = ((m * NCH + c + 1) * 2 + h) * 32 + t;
-#if SP3D_WG_ABLATE & 8
-                    n0[m] = u32x4{(unsigned)idx, 1u, 2u, (unsigned)c}; n1[m] = n0[m] ^ 3u;
-#else
-                    n0[m] = wg_lds[idx]; n1[m] = wg_lds[QPLANE + idx];
-#endif
-                }
-            }
-#if SP3D_WG_ABLATE & 2
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m][c & 15] += __uint_as_float((a0[m].x ^ b[c].hl.x ^ a1[m].y ^ b[c].hh.z ^ b[c].mm.w) & 0x3fffffffu);
-#else
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a0[m], b[c].hl, acc[m]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a1[m], b[c].hh, acc[m]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = mfma_bf16(a1[m], b[c].mm, acc[m]);
-#endif
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { a0[m] = n0[m]; a1[m] = n1[m]; }
-        }
-        // D: lane (column t, h) holds rows 8 (v >> 2) + (v & 3) + 4 h of each row block: 128-byte runs per row
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = row0 + 32 * m + 8 * (v >> 2) + (v & 3) + 4 * h;
-#if SP3D_WG_ABLATE & 1
-                if (acc[m][v] == 123.456f)
-#endif
-                if (row < T) Mp[(int64_t)row * O + 32 * wave + t] = acc[m][v];
-            }
-    }
-}
 
 } // namespace sp3d
 
@@ -1489,15 +1222,6 @@ extern "C" int sp3d_wino_fused_split(const float *x, const void *U3, float *y, c
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
-static int g_w16_nbw = 0, g_w16_ks = 1;          // 0: chosen per launch (below); tools/exp_wino_split.py overrides
-extern "C" int sp3d_debug_set_w16_nbw(int nbw, int ks)
-{
-    if ((nbw != 0 && nbw != 1 && nbw != 2 && nbw != 4) || (ks != 1 && ks != 2)) return SP3D_EINVAL;
-    g_w16_nbw = nbw;
-    g_w16_ks = ks;
-    return SP3D_OK;
-}
-
 extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const float *shift, const float *residual,
                                        int mode, int B, int X, int Y, int Z, int C, int O, void *stream)
 {
@@ -1508,43 +1232,32 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
     const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 1) / 2;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
-    // waves per block: two output groups x two input-channel groups of one wave each (2 waves per SIMD resident).
-    // Measured at (4,64,40,40,10) / (4,32,40,40,10) / (8,64,32,32,32): tools/exp_wino_split.py --half
-    int nbw = g_w16_nbw, ks = g_w16_ks;
-    if (nbw == 0) {
-        nbw = 2; ks = 2;               // 4 waves per block, 2 per SIMD: best on all three shapes
-    }
-    if ((C / 16) % ks) return SP3D_EUNSUPPORTED;
+    // waves per block: two output groups x two input-channel groups of one wave each (2 waves per SIMD resident): best of the
+    // {1,2,4} x {1,2} configurations measured at (4,64,40,40,10) / (4,32,40,40,10) / (8,64,32,32,32) in round 2; the others
+    // are no longer instantiated
+    constexpr int nbw = 2, ks = 2;
     const dim3 grid((unsigned)blocks), block(64 * (4 / nbw) * ks);
     hipStream_t s = (hipStream_t)stream;
     const unsigned *u3 = reinterpret_cast<const unsigned *>(U3);
-#define SP3D_WF(C_, M_, N_, K_) hipLaunchKernelGGL((wino_fused16_kernel<C_, M_, N_, K_>), grid, block, 0, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
-#define SP3D_WFN(C_, M_) { if (nbw == 1 && ks == 1) SP3D_WF(C_, M_, 1, 1); else if (nbw == 2 && ks == 1) SP3D_WF(C_, M_, 2, 1); else if (nbw == 4 && ks == 1) SP3D_WF(C_, M_, 4, 1); \
-                           else if (nbw == 2 && ks == 2) SP3D_WF(C_, M_, 2, 2); else if (nbw == 4 && ks == 2) SP3D_WF(C_, M_, 4, 2); else return SP3D_EUNSUPPORTED; }
-#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WFN(C_, 0); break; case 1: SP3D_WFN(C_, 1); break; case 2: SP3D_WFN(C_, 2); break; default: SP3D_WFN(C_, 3); }
+#define SP3D_WF(C_, M_) hipLaunchKernelGGL((wino_fused16_kernel<C_, M_, 2, 2>), grid, block, 0, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
+#define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }
     if (C == 32) { SP3D_WFM(32) } else { SP3D_WFM(64) }
 #undef SP3D_WFM
-#undef SP3D_WFN
 #undef SP3D_WF
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
-extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W3, float *y, void *ys, const float *shift,
-                                   const float *residual, int mode, int B, int X, int Y, int Z, int C, int O, void *stream)
+extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,
+                                int B, int X, int Y, int Z, int C, int O, void *stream)
 {
     using namespace sp3d;
     if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
-    if ((!x && !xs) || !W3 || (!y && !ys) || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
+    if (!x || !W3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
     if (O != 32 || (C != 16 && C != 32) || (reinterpret_cast<uintptr_t>(W3) & 15)) return SP3D_EUNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(xs) & 15) || (reinterpret_cast<uintptr_t>(ys) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
-        return SP3D_EUNSUPPORTED;
-    if (ys && mode != 1 && mode != 2) return SP3D_EUNSUPPORTED;                 // split results: the two modes V2V uses
-    if (xs && C != 32) return SP3D_EUNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(y) & 15) return SP3D_EUNSUPPORTED;
     if ((int64_t)X * Y * Z * C * 2 > 0x7fffffff) return SP3D_ERANGE;
     const int NBX = (X + CD_BX - 1) / CD_BX, NBY = (Y + CD_BY - 1) / CD_BY, NBZ = (Z + CD_BZ - 1) / CD_BZ;
-    // 32-bit byte offsets inside one staged region of the zero-bordered split tensor
-    if ((xs || ys) && (int64_t)(CD_RX + 1) * cd_pad(Y, CD_BY) * cd_pad(Z, CD_BZ) * 64 > 0x7fffffff) return SP3D_ERANGE;
     const int64_t blocks = (int64_t)B * NBX * NBY * NBZ;
     if (blocks > 0x7fffffff) return SP3D_ERANGE;
     static int cu_count[64] = {0};                     // per device, queried once (hipGetDeviceProperties is slow)
@@ -1562,74 +1275,19 @@ extern "C" int sp3d_conv3_split_ex(const float *x, const void *xs, const void *W
     const dim3 grid((unsigned)nwg), block(64 * (4 + CD_PROD));
     const size_t lds = (size_t)2 * CD_BUFS * sizeof(unsigned) + 4 * 1024 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3), *xs3 = reinterpret_cast<const unsigned *>(xs);
-    unsigned *ys3 = reinterpret_cast<unsigned *>(ys);
-    const int out = (y ? 1 : 0) | (ys ? 2 : 0);
+    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3);
     // the attribute is per device: remember it per device (a process that drives several GPUs launches on each)
     int cd_dev = 0;
     { const hipError_t ed = hipGetDevice(&cd_dev); if (ed != hipSuccess) return (int)ed; }
     if (cd_dev < 0 || cd_dev >= 64) cd_dev = 63;
-#define SP3D_CD(C_, M_, I_, O_) { static bool attr_dev[64] = {}; bool &attr = attr_dev[cd_dev]; if (!attr || cd_dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_, I_, O_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
-    hipLaunchKernelGGL((conv3_split_kernel<C_, M_, I_, O_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks, xs3, ys3); }
-#define SP3D_CDO(C_, M_, I_) { if (out == 1) SP3D_CD(C_, M_, I_, 1) else if (out == 2) SP3D_CD(C_, M_, I_, 2) else SP3D_CD(C_, M_, I_, 3) }
-#define SP3D_CDI(C_, I_) switch (mode) { case 0: SP3D_CD(C_, 0, I_, 1); break; case 1: SP3D_CDO(C_, 1, I_); break; case 2: SP3D_CDO(C_, 2, I_); break; default: SP3D_CD(C_, 3, I_, 1); }
-    if (C == 16) { SP3D_CDI(16, false) }
-    else if (xs) { SP3D_CDI(32, true) }
-    else { SP3D_CDI(32, false) }
+#define SP3D_CD(C_, M_) { static bool attr_dev[64] = {}; bool &attr = attr_dev[cd_dev]; if (!attr || cd_dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_split_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
+    hipLaunchKernelGGL((conv3_split_kernel<C_, M_>), grid, block, lds, s, x, w3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ, (int)blocks); }
+#define SP3D_CDI(C_) switch (mode) { case 0: SP3D_CD(C_, 0); break; case 1: SP3D_CD(C_, 1); break; case 2: SP3D_CD(C_, 2); break; default: SP3D_CD(C_, 3); }
+    if (C == 16) { SP3D_CDI(16) } else { SP3D_CDI(32) }
 #undef SP3D_CDI
-#undef SP3D_CDO
 #undef SP3D_CD
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
-}
-
-extern "C" int sp3d_wino_gemm_split(const float *V, const void *W3, float *M, int P, int T, int C, int O, void *stream)
-{
-    using namespace sp3d;
-    if (!V || !W3 || !M) return SP3D_ENULL;
-    if (P <= 0 || T <= 0) return SP3D_EINVAL;
-    if (O != 128 || (C != 64 && C != 128) || (reinterpret_cast<uintptr_t>(W3) & 15) || (reinterpret_cast<uintptr_t>(V) & 15))
-        return SP3D_EUNSUPPORTED;
-    if ((int64_t)T * 128 > 0x7fffffff) return SP3D_ERANGE;
-    int dev = 0;
-    { const hipError_t ed = hipGetDevice(&dev); if (ed != hipSuccess) return (int)ed; }
-    if (dev < 0 || dev >= 64) dev = 63;
-    static int cu_count[64] = {0};
-    if (cu_count[dev] == 0) {
-        int n = 0;
-        cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    // one workgroup per CU (its operand planes are 8 KB per channel chunk), an equal share of the points' row tiles each
-    const int ntile = (T + 127) / 128;
-    int G = cu_count[dev] / P;
-    if (G < 1) G = 1;
-    if (G > ntile) G = ntile;
-    const dim3 grid((unsigned)(P * G)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned *w3 = reinterpret_cast<const unsigned *>(W3);
-#define SP3D_WG(NCH_) { const size_t lds = (size_t)2 * 4 * NCH_ * 2 * 32 * 16; static bool attr_dev[64] = {}; bool &attr = attr_dev[dev]; \
-    if (!attr || dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_split_kernel<NCH_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (ea != hipSuccess) return (int)ea; attr = true; } \
-    hipLaunchKernelGGL((wino_gemm_split_kernel<NCH_>), grid, block, lds, s, V, w3, M, T, G); }
-    if (C == 128) SP3D_WG(16) else SP3D_WG(8)
-#undef SP3D_WG
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SP3D_OK : (int)e;
-}
-
-extern "C" int sp3d_conv3_s3_dims(int X, int Y, int Z, int *padded3)
-{
-    using namespace sp3d;
-    if (!padded3) return SP3D_ENULL;
-    if (X <= 0 || Y <= 0 || Z <= 0) return SP3D_EINVAL;
-    padded3[0] = cd_pad(X, CD_BX); padded3[1] = cd_pad(Y, CD_BY); padded3[2] = cd_pad(Z, CD_BZ);
-    return SP3D_OK;
-}
-
-extern "C" int sp3d_conv3_split(const float *x, const void *W3, float *y, const float *shift, const float *residual, int mode,
-                                int B, int X, int Y, int Z, int C, int O, void *stream)
-{
-    if (!x || !y) return SP3D_ENULL;
-    return sp3d_conv3_split_ex(x, nullptr, W3, y, nullptr, shift, residual, mode, B, X, Y, Z, C, O, stream);
 }
 
 extern "C" int sp3d_debug_conv3_timeline(void *dev_buffer)

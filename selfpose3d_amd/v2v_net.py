@@ -236,8 +236,6 @@ class _FoldedV2V:
                     u._sp3d_split = _lib.wino_weights_split(u)
                 elif u is not None and u.shape[2] == 64 and u.shape[1] in (32, 64):
                     u._sp3d_split = _lib.wino_weights_split(u, 16)
-                elif u is not None and u.shape[2] == 128 and u.shape[1] in (64, 128):
-                    u._sp3d_gemm = _lib.wino_gemm_weights_split(u)   # quarter resolution: own split GEMM between the transforms
             if len(blk.skip_con) > 0:
                 ws, ss = self._fold(blk.skip_con[0], blk.skip_con[1])
                 t[name] = (w1, s1, w2, (s2 + ss).contiguous(), ws, u1, u2)
@@ -272,8 +270,7 @@ class _FoldedV2V:
                 # (MIOpen) at (4,32->64,40,40,10)
                 return _lib.wino_fused_conv3d_(x, u, shift, mode, residual, u3)
             if C >= 128 or (C >= 64 and 64 * T * C * 4 <= 160e6):
-                w3g = getattr(u, "_sp3d_gemm", None) if getattr(self.net, "wino_split", True) and getattr(self.net, "split_gemm", False) else None
-                return _lib.wino_conv3d_(x, u, shift, mode, residual, w3g)
+                return _lib.wino_conv3d_(x, u, shift, mode, residual)
             w3 = getattr(u, "_sp3d_direct", None) if getattr(self.net, "wino_split", True) and getattr(self.net, "direct_conv", True) else None
             if w3 is not None and C in (16, 32) and u.shape[2] == 32:
                 # implicit GEMM with exact three-piece bf16 splits: no Winograd transforms (which made the fused kernel
@@ -472,53 +469,10 @@ class _FoldedV2V:
         y = y.contiguous(memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
         return _lib.channel_shift_act_(y, s0, 1)
 
-    def _s3_ok(self, x, name):
-        """both convs of a full-resolution block on the direct split kernel: chain them through split (S3) tensors.
-        OPT-IN (V2VNet.s3_chain): a layer that reads split input is 3-8 % faster (137.6 / 140.8 us against 149.4 / 144.5 at
-        (4,32,80,80,20): its loader waves only issue LDS-DMA), but the layer before it pays 10-25 us for writing 2x the
-        bytes in 16-byte pieces (tools/exp_wino_split.py, round 3): the root-net step is 1.665 ms chained, 1.57 ms not."""
-        w1, _, w2, _, _, u1, u2 = self.t[name]
-        return bool(getattr(self.net, "s3_chain", False) and getattr(self.net, "wino_split", True)
-                    and getattr(self.net, "direct_conv", True) and self.net.winograd and x.is_cuda
-                    and x.dtype == torch.float32 and self._is_cl(x) and u1 is not None and u2 is not None
-                    and getattr(u1, "_sp3d_direct", None) is not None and getattr(u2, "_sp3d_direct", None) is not None
-                    and int(w2.shape[1]) == 32)
-
-    def _s3_buffer(self, tag, B, X, Y, Z, C, device):
-        """zero-bordered split tensor owned by the plan (zeroed once: the kernels never write the border)"""
-        from . import _lib
-        key = ("s3", tag, B, X, Y, Z, C, str(device))
-        buf = self.t.get(key)
-        if buf is None:
-            buf = self.t[key] = _lib.conv3_s3_empty(B, X, Y, Z, C, device)
-        return buf
-
-    def _res_s3(self, x, name, x_s3=None, want_s3=False):
-        """Res3DBlock with the hidden activation (and optionally the input / the result) in split form: the second conv's
-        loader waves move 16-byte records with LDS-DMA instead of splitting fp32 values next to the matrix stream"""
-        from . import _lib
-        w1, s1, w2, s2, ws, u1, u2 = self.t[name]
-        B, _, X, Y, Z = (int(v) for v in x.shape)
-        h3 = self._s3_buffer("hidden", B, X, Y, Z, 32, x.device)
-        if x_s3 is not None:
-            _lib.conv3_split_(None, u1._sp3d_direct, s1, 1, None, x_s3=x_s3, want_f32=False, want_s3=True, out_s3=h3,
-                              dims=(X, Y, Z))
-        else:
-            _lib.conv3_split_(x, u1._sp3d_direct, s1, 1, None, want_f32=False, want_s3=True, out_s3=h3)
-        r = x if ws is None else self._conv1(x, ws)
-        if want_s3:
-            o3 = self._s3_buffer("block", B, X, Y, Z, 32, x.device)
-            return _lib.conv3_split_(None, u2._sp3d_direct, s2, 2, r, x_s3=h3, want_s3=True, out_s3=o3)
-        return _lib.conv3_split_(None, u2._sp3d_direct, s2, 2, r, x_s3=h3), None
-
     def _tail(self, x):
         from . import _lib
-        if self._s3_ok(x, "front_res") and self._s3_ok(x, "skip_res1"):
-            x, x3 = self._res_s3(x, "front_res", None, True)
-            skip1, _ = self._res_s3(x, "skip_res1", x3, False)
-        else:
-            x = self._res(x, "front_res")
-            skip1 = self._res(x, "skip_res1")
+        x = self._res(x, "front_res")
+        skip1 = self._res(x, "skip_res1")
         x = self._res(self._pool(x), "encoder_res1")
         skip2 = self._res(x, "skip_res2")
         x = self._res(self._pool(x), "encoder_res2")
@@ -577,11 +531,6 @@ class V2VNet(nn.Module):
         self.zdft = True                 # ... root grid: direct z-DFTs + dense 2-D transforms instead of the 3-D real plans
         self.wino_split = True           # ... fused Winograd layers: exact 3-piece bf16 splits on the bf16 matrix pipe
         self.direct_conv = True          # ... full-resolution 3x3x3 layers: direct (implicit GEMM) split convolution
-        self.split_gemm = False          # ... quarter-resolution Winograd products on the own split-bf16 batched GEMM instead of the
-                                         # library's fp32 one: opt-in, measured 45 vs 36 us (C=128) / 27 vs 39 us (C=64) per product
-                                         # with library heuristics, 27.7 / 25.2 us with TunableOp - the product is memory- and
-                                         # latency-bound at 64 x (1200 x 128 x 128) (tools/bench_wino_gemm.py)
-        self.s3_chain = False            # ... chained through split activations (LDS-DMA loaders): measured, no gain - off
         self._plan = None
         self.reset_parameters()
 

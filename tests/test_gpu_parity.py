@@ -90,34 +90,6 @@ def test_nhwc_variants_bit_identical(dev, variant):
     assert torch.equal(base, got)
 
 
-@pytest.mark.parametrize("name", gio.SMALL_CASES + gio.FULL_CASES)
-def test_patch_kernel_bit_identical(dev, name):
-    """LDS-staged patch kernel (variant 128, sp3d_unproject_patch.hip) == the planar kernel, bit for bit, in both result
-    layouts, on every golden case with 13-16 channels (coarse, fine, augmented, invalid rows, V=10 stress grid): whatever
-    mix of staged patches / direct-gather fall-backs the workgroups take, the values are the same."""
-    from selfpose3d_amd import _lib
-    case = gio.Case(name)
-    if case.J <= 12 or min(case.hm) < 2:
-        pytest.skip("the patch kernel takes 16-float pixels")
-    base, _ = _hip_fwd(case, dev, "planar")
-    got, grids = _hip_fwd(case, dev, "nhwc", variant=128, want_grids=True)
-    assert torch.equal(base, got)
-    _, ref_g = _oracle_fwd(case)
-    assert np.array_equal(grids.cpu().numpy(), ref_g)
-    # channels-last result (B, X, Y, Z, 16): the 16 packed channels, pad channel = 0
-    w, h = case.hm
-    hms = [x.to(dev) for x in case.hms]
-    packed = _lib.pack_heatmaps(hms, jp=16)
-    cam = torch.from_numpy(case.cam).to(dev)
-    centers = torch.from_numpy(case.centers).to(dev)
-    valid = torch.from_numpy(case.valid).to(dev)
-    cl, _ = _lib.unproject_fwd([packed[c] for c in range(case.V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, case.B, 16,
-                               h, w, case.cube, case.grid_size, case.img, False, variant=128, channels_last=True)
-    assert tuple(cl.shape) == (case.B, 16, *case.cube)          # a (B,16,X,Y,Z) view of (B,X,Y,Z,16) memory
-    assert torch.equal(cl[:, :case.J], base)
-    assert torch.count_nonzero(cl[:, case.J:]) == 0
-
-
 def test_no_grids_and_invalid_rows(dev):
     case = gio.Case("unproj_fine_small")          # row 1 is invalid (flag < 0)
     for layout in ("planar", "nhwc"):
@@ -1194,85 +1166,3 @@ def test_winograd_split_kernels_confine_nonfinite_inputs(kind):
     assert bool((~torch.isfinite(y))[~torch.isfinite(refnf)].all())          # superset of the direct convolution's pattern
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("dims", [(2, (16, 12, 8)), (1, (9, 7, 5)), (1, (40, 24, 10))])
-def test_direct_conv3_split_activation_chain(dims):
-    """two layers chained through the split (S3) activation format: conv1 writes ONLY the (zero-bordered, block-padded) S3
-    tensor, conv2 reads it pre-split (LDS-DMA loaders) and adds the residual - bit-identical to the same two layers through
-    fp32 tensors (the split is exact), the S3 tensor decodes to conv1's fp32 output bit for bit, and its border stays zero"""
-    from selfpose3d_amd import _lib
-    B, (X, Y, Z) = dims
-    g = torch.Generator(device="cpu").manual_seed(31)
-    x = (torch.randn((B, 32, X, Y, Z), generator=g) * 2.0).cuda().contiguous(memory_format=torch.channels_last_3d)
-    w1 = (torch.randn((32, 32, 3, 3, 3), generator=g) * 0.05).cuda()
-    w2 = (torch.randn((32, 32, 3, 3, 3), generator=g) * 0.05).cuda()
-    s1, s2 = torch.randn(32, generator=g).cuda(), torch.randn(32, generator=g).cuda()
-    W1, W2 = _lib.conv_weights_split(w1), _lib.conv_weights_split(w2)
-    h = _lib.conv3_split_(x, W1, s1, 1)
-    want = _lib.conv3_split_(h, W2, s2, 2, x)
-    none, h3 = _lib.conv3_split_(x, W1, s1, 1, want_f32=False, want_s3=True)
-    PX, PY, PZ = _lib.conv3_s3_dims(X, Y, Z)
-    assert (PX, PY, PZ) == ((X + 15) // 16 * 16 + 2, (Y + 7) // 8 * 8 + 2, (Z + 3) // 4 * 4 + 2)
-    assert none is None and h3.shape == (B, 4, PX, PY, PZ, 2, 8)
-    border = h3.clone()
-    border[:, :, 1:X + 1, 1:Y + 1, 1:Z + 1] = 0
-    assert int(border.abs().max()) == 0
-    # decode: dwords [lo01 lo23 hi01 hi23 | hi01 hi23 mid01 mid23], each two bf16 (low half = first channel)
-    core = h3[:, :, 1:X + 1, 1:Y + 1, 1:Z + 1].permute(0, 2, 3, 4, 1, 5, 6).reshape(B, X, Y, Z, 8, 8).contiguous()
-    d = core.view(torch.int16).view(B, X, Y, Z, 8, 8, 2).view(torch.bfloat16).float()      # [..., dword, pair]
-    lo = torch.cat([d[..., 0, :], d[..., 1, :]], -1)
-    hi = torch.cat([d[..., 2, :], d[..., 3, :]], -1)
-    mid = torch.cat([d[..., 6, :], d[..., 7, :]], -1)
-    back = ((hi + mid) + lo).reshape(B, X, Y, Z, 32).permute(0, 4, 1, 2, 3)
-    assert torch.equal(back, h)
-    got, got3 = _lib.conv3_split_(None, W2, s2, 2, x, x_s3=h3, want_s3=True)
-    assert torch.equal(got, want)
-    both = _lib.conv3_split_(x, W1, s1, 1, want_s3=True)
-    assert torch.equal(both[0], h) and torch.equal(both[1], h3)
-    # a reused S3 tensor (what the inference plan does): same result, border still zero
-    again = _lib.conv3_split_(None, W2, s2, 2, x, x_s3=h3, want_s3=True, out_s3=got3)
-    assert torch.equal(again[0], want) and again[1] is got3
-    # split input, no fp32 tensor anywhere: the volume's extents come from dims
-    only3 = _lib.conv3_split_(None, W2, s2, 1, None, x_s3=h3, dims=(X, Y, Z))
-    assert torch.equal(only3, _lib.conv3_split_(h, W2, s2, 1))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(64, 1200, 128), (64, 1200, 64), (64, 75, 128), (3, 300, 64), (64, 129, 128)])
-def test_wino_gemm_split_vs_float64(shape):
-    """sp3d_wino_gemm_split (the quarter-resolution Winograd products as exact three-piece bf16 splits, fp32 accumulation)
-    against a float64 product: error <= 1.5x that of the fp32 library GEMM it replaces (+ 1e-7 of the output range), ragged
-    row counts (last 128-row tile partial, fewer rows than one tile) included"""
-    from selfpose3d_amd import _lib
-    P, T, Cc = shape
-    g = torch.Generator(device="cpu").manual_seed(41)
-    V = (torch.randn((P, T, Cc), generator=g) * 2.0).cuda()
-    U = (torch.randn((P, Cc, 128), generator=g) * 0.05).cuda()
-    W3 = _lib.wino_gemm_weights_split(U)
-    M = _lib.wino_gemm_split(V, W3)
-    ref = torch.bmm(V.double(), U.double())
-    lib32 = torch.bmm(V, U)
-    e_own = float((M.double() - ref).abs().max())
-    e_lib = float((lib32.double() - ref).abs().max())
-    scale = float(ref.abs().max())
-    assert e_own <= 1.5 * e_lib + 1e-7 * scale, (e_own, e_lib, scale)
-    # rows are independent: a row-permuted input gives the row-permuted output bit for bit
-    perm = torch.randperm(T, generator=g).cuda()
-    assert torch.equal(_lib.wino_gemm_split(V[:, perm].contiguous(), W3), M[:, perm])
-
-
-@pytest.mark.gpu
-def test_quarter_resolution_layer_split_gemm_vs_library_gemm():
-    """the three-launch Winograd layer with the split GEMM against the same layer with torch.bmm, both against float64"""
-    from selfpose3d_amd import _lib
-    g = torch.Generator(device="cpu").manual_seed(43)
-    x = torch.randn((4, 128, 20, 20, 5), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
-    w = (torch.randn((128, 128, 3, 3, 3), generator=g) * 0.03).cuda()
-    shift = torch.randn(128, generator=g).cuda()
-    res = torch.randn((4, 128, 20, 20, 5), generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
-    U = _lib.wino_weights(w)
-    y_own = _lib.wino_conv3d_(x, U, shift, 2, res, _lib.wino_gemm_weights_split(U))
-    y_lib = _lib.wino_conv3d_(x, U, shift, 2, res)
-    ref = (torch.nn.functional.conv3d(x.double(), w.double(), padding=1) + shift.double().view(1, -1, 1, 1, 1) + res.double()).clamp_min(0)
-    e_own, e_lib = float((y_own.double() - ref).abs().max()), float((y_lib.double() - ref).abs().max())
-    assert e_own <= 1.5 * e_lib + 1e-7 * float(ref.abs().max()), (e_own, e_lib)
