@@ -77,6 +77,9 @@ def parse():
                     help="box_spread: the timed K steps + this many - 1 further repeats of K steps (min / max ms_per_step)")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-graph", choices=["on", "off"], default="on",
+                    help="train_step leg: the 2-D backbone's per-view forward + backward as HIP graphs "
+                         "(torch.cuda.make_graphed_callables, selfpose3d_amd/graphs.py graph_backbone_views)")
     ap.add_argument("--train-find", choices=["search", "immediate"], default="search",
                     help="MIOpen kernel selection for the train_step leg: search (cudnn.benchmark, one-off minutes) or immediate")
     return ap.parse_args()
@@ -570,11 +573,19 @@ def train_step_leg(args, rank, world, dev):
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
     find_unused = D.needs_find_unused(cfg)
-    ddp = D.wrap_ddp(model, dev, find_unused=find_unused)
     ds = SyntheticPanoptic(cfg, num_frames=Bt, seed=D.rank_seed(1, rank) % 100000, max_people=3)
     inputs, t2d, w2d, t3d, meta, _ = default_collate([ds[i] for i in range(Bt)])
     inputs = [x.to(dev).contiguous(memory_format=torch.channels_last) for x in inputs]
     t2d, w2d, t3d0 = [x.to(dev) for x in t2d], [x.to(dev) for x in w2d], t3d[0].to(dev)
+    graphed = False
+    if args.train_graph == "on" and model.backbone is not None:
+        # the five per-view ResNet-50 passes are ~95 % of the step's kernel launches: forward + backward as HIP graphs (same
+        # kernels, same order), captured before the DDP wrap
+        from selfpose3d_amd.graphs import graph_backbone_views
+        model.train()
+        graph_backbone_views(model.backbone, inputs)
+        graphed = True
+    ddp = D.wrap_ddp(model, dev, find_unused=find_unused)
 
     def gt_proposals(grid_centers, m):
         gc = torch.zeros_like(grid_centers)
@@ -618,7 +629,7 @@ def train_step_leg(args, rank, world, dev):
                              "DDP gradient all-reduce over RCCL (backend nccl)") + ", bucket_cap 32 MB, overlapped with backward")
                            if world > 1 else "none (single process)"),
             "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
-            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
+            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "backbone_hip_graphs": graphed, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
             "loss_last": float(state["loss"]), "data": "synthetic frames built once per rank, resident on the device",
             "config": "configs/panoptic_synthetic_960x512_cam5.yaml (ResNet-50, 80x80x20 root grid, 64^3 pose cubes)"}
 
