@@ -77,9 +77,6 @@ def parse():
                     help="box_spread: the timed K steps + this many - 1 further repeats of K steps (min / max ms_per_step)")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-warmup", type=int, default=3)
-    ap.add_argument("--train-graph", choices=["on", "off"], default="on",
-                    help="train_step leg: the 2-D backbone's per-view forward + backward as HIP graphs "
-                         "(torch.cuda.make_graphed_callables, selfpose3d_amd/graphs.py graph_backbone_views)")
     ap.add_argument("--train-find", choices=["search", "immediate"], default="search",
                     help="MIOpen kernel selection for the train_step leg: search (cudnn.benchmark, one-off minutes) or immediate")
     return ap.parse_args()
@@ -577,14 +574,6 @@ def train_step_leg(args, rank, world, dev):
     inputs, t2d, w2d, t3d, meta, _ = default_collate([ds[i] for i in range(Bt)])
     inputs = [x.to(dev).contiguous(memory_format=torch.channels_last) for x in inputs]
     t2d, w2d, t3d0 = [x.to(dev) for x in t2d], [x.to(dev) for x in w2d], t3d[0].to(dev)
-    graphed = False
-    if args.train_graph == "on" and model.backbone is not None:
-        # the five per-view ResNet-50 passes are ~95 % of the step's kernel launches: forward + backward as HIP graphs (same
-        # kernels, same order), captured before the DDP wrap
-        from selfpose3d_amd.graphs import graph_backbone_views
-        model.train()
-        graph_backbone_views(model.backbone, inputs)
-        graphed = True
     ddp = D.wrap_ddp(model, dev, find_unused=find_unused)
 
     def gt_proposals(grid_centers, m):
@@ -629,8 +618,8 @@ def train_step_leg(args, rank, world, dev):
                              "DDP gradient all-reduce over RCCL (backend nccl)") + ", bucket_cap 32 MB, overlapped with backward")
                            if world > 1 else "none (single process)"),
             "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
-            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "backbone_hip_graphs": graphed, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
-            "loss_last": float(state["loss"]), "data": "synthetic frames built once per rank, resident on the device",
+            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
+            "loss_last": float(state["loss"].detach()), "data": "synthetic frames built once per rank, resident on the device",
             "config": "configs/panoptic_synthetic_960x512_cam5.yaml (ResNet-50, 80x80x20 root grid, 64^3 pose cubes)"}
 
 

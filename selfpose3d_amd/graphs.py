@@ -67,36 +67,3 @@ class GraphedRootNet:
         return self.out
 
 
-
-class _ViewPass(torch.nn.Module):
-    """one view's pass through a SHARED backbone: a distinct callable per view, because a graphed callable keeps ONE set of
-    saved activations - its forward may not run again before its backward has"""
-
-    def __init__(self, backbone):
-        super().__init__()
-        self.backbone = backbone
-
-    def forward(self, x):
-        return self.backbone(x)
-
-
-def graph_backbone_views(backbone, sample_views: Sequence[torch.Tensor], warmup: int = 3):
-    """Training: capture the 2-D backbone's forward AND backward of every view as HIP graphs
-    (``torch.cuda.make_graphed_callables``): the per-view passes of a ResNet-50 are ~95 % of a train step's ~7 000 kernel
-    launches (861 x 3 BatchNorm-backward kernels, 2 656 element-wise adds ... profiles/r03_train_step_kernels.md), the step was
-    74 % GPU-busy, and eight such host-bound processes on one node are where near-linear scaling goes to die (round-3 review).
-    The same kernels run in the same order on the same operands - gradients and BatchNorm statistics are those of the eager
-    passes.  Call BEFORE wrapping the model in DistributedDataParallel (the parameter gradients leave the graphed backward as
-    ordinary autograd outputs, so DDP's bucket hooks fire as usual) and with the backbone in the mode it will train in; the
-    graphs are used by ``PoseResNet.forward_views`` while the views keep the sample's shape / memory format, eager otherwise.
-    Reference loop being replaced: lib/models/multi_person_posenet.py:44-48 (one backbone call per view)."""
-    if not sample_views[0].is_cuda:
-        raise _lib.Sp3dError("graph_backbone_views: CUDA tensors expected")
-    passes = tuple(_ViewPass(backbone) for _ in sample_views)
-    for p in passes:
-        p.train(backbone.training)
-    samples = tuple((v.detach().clone(),) for v in sample_views)
-    graphed = torch.cuda.make_graphed_callables(passes, samples, num_warmup_iters=int(warmup))
-    backbone._graphed_views = list(graphed)
-    backbone._graphed_key = (tuple(sample_views[0].shape), sample_views[0].stride(), sample_views[0].dtype, bool(backbone.training))
-    return backbone

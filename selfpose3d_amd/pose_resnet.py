@@ -123,10 +123,6 @@ class PoseResNet(nn.Module):
         result IS the (V,B,h,w,Jp) buffer the unprojection kernel gathers from; the returned per-view tensors are
         (B,J,h,w) views of it (``project_layer.nhwc_heatmap_views``) and the re-tiling pass disappears."""
         if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
-            g = getattr(self, "_graphed_views", None)
-            if g is not None and len(g) == len(views) and torch.is_grad_enabled() and all(
-                    (tuple(v.shape), v.stride(), v.dtype, True) == self._graphed_key for v in views):
-                return [gv(v) for gv, v in zip(g, views)]          # HIP-graphed forward + backward per view (graphs.py)
             return [self.forward(v) for v in views]
         V, B = len(views), views[0].shape[0]
         x = torch.cat(list(views), 0).contiguous(memory_format=torch.channels_last)

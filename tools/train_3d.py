@@ -40,9 +40,6 @@ def main():
     ap.add_argument("--cfg", required=True)
     ap.add_argument("--frames", type=int, default=32, help="synthetic frames per epoch (global)")
     ap.add_argument("--max-iters", type=int, default=None)
-    ap.add_argument("--graph-backbone", action="store_true",
-                    help="supervised model, TRAIN_BACKBONE: the per-view backbone forward + backward as HIP graphs "
-                         "(selfpose3d_amd/graphs.py graph_backbone_views; same kernels, ~20x fewer launches per step)")
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "train")
     torch.manual_seed(D.rank_seed(int(cfg.get("SEED", 0)), rank))       # per-rank streams (sampling, augmentation)
@@ -60,11 +57,6 @@ def main():
     params = select_trainable(model, cfg)
     optimizer = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
     start, best, last = (load_checkpoint(model, optimizer, out) if cfg.TRAIN.RESUME else (int(cfg.TRAIN.BEGIN_EPOCH), 0.0, -1))
-    if args.graph_backbone and device.type == "cuda" and not ssv and model.backbone is not None and cfg.NETWORK.TRAIN_BACKBONE:
-        from selfpose3d_amd.graphs import graph_backbone_views
-        first = next(iter(train_loader))[0]                             # list[V] of (B,3,H,W): shapes of every later batch
-        model.train()
-        graph_backbone_views(model.backbone, [v.to(device) for v in first])
     ddp = D.wrap_ddp(model, device, find_unused=D.needs_find_unused(cfg))
     sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, list(cfg.TRAIN.LR_STEP), float(cfg.TRAIN.LR_FACTOR),
                                                  last_epoch=last)
