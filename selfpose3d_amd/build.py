@@ -33,7 +33,12 @@ def needs_build() -> bool:
 # per-source extra flags.  sp3d_winograd.hip: no SLP vectorisation - next to matrix instructions the v_pk_add_f32 /
 # v_pk_fma_f32 the vectoriser forms out of the operand transforms cost more than the scalar instructions they replace
 # (half-resolution fused Winograd kernel 83.4 -> 78.5 us); the unprojection kernels, on the other hand, want it.
-PER_SOURCE_FLAGS = {"sp3d_winograd.hip": ["-fno-slp-vectorize"]}
+PER_SOURCE_FLAGS = {"sp3d_winograd.hip": ["-fno-slp-vectorize"],
+                    # round 4: compiler-formed v_pk_*_f32 in these kernels come out WRONG when waves of wino_fused16_kernel
+                    # (v_mfma_f32_16x16x32_bf16) are resident on the same CU - two plans on one GPU, streams or processes
+                    # (profiles/r04_gpu_sharing_finding.md); without the vectoriser they are immune, at the same speed
+                    # (bench step 1.563 vs 1.569 ms)
+                    "sp3d_fft.hip": ["-fno-slp-vectorize"], "sp3d_fftconv.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile_objects(objdir: str, extra_flags=(), verbose: bool = False):

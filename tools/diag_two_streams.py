@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 from selfpose3d_amd import _lib
+if os.environ.get("SP3D_LIB"):                      # a measurement build (e.g. -DSP3D_W16_ABLATE=mask) instead of the shipped library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SP3D_LIB"])
+ONLY_FIRST = bool(os.environ.get("DIAG_ONLY_FIRST"))
 dev = torch.device("cuda:0")
 cfg, meta, hms, model, golden = bench.build_workload(4, 0, dev, "cl3d", "fft", True, False, False)
 g = torch.Generator().manual_seed(5)
@@ -21,7 +24,13 @@ with torch.no_grad():
     a32 = torch.rand(8192, 1024, generator=g).to(dev); w32 = torch.rand(1024, 1024, generator=g).to(dev)
     big = torch.rand(64 * 1024 * 1024, generator=g).to(dev)
     shift = torch.rand(16, generator=g).to(dev); x16 = cl(4, 16, 80, 80, 20)
-    victims = {"freq_contract": lambda: _lib.freq_contract(sp5, wz),
+    pl = model.project_layer
+
+    def unproj():
+        c, _ = pl.get_voxel(hms, meta, model.grid_size, [model.grid_center], model.cube_size, want_grids=False,
+                            pad_channels=True, channels_last=True)
+        return c
+    victims = {"unprojection (brick kernel, explicit v_pk)": unproj, "freq_contract": lambda: _lib.freq_contract(sp5, wz),
                "cfft2d_88 fwd+inv": lambda: _lib.cfft2d_(_lib.cfft2d_(spec0.clone(), False, rows_in=80), True, rows_out=80),
                "zdft_fwd": lambda: torch.view_as_real(_lib.zdft_fwd_cl(x16, 16, (88, 88, 28))),
                "library fp32 GEMM": lambda: a32 @ w32,
@@ -36,9 +45,11 @@ with torch.no_grad():
     torch.cuda.synchronize()
     out = {}
     for an, afn in aggressors.items():
+        if ONLY_FIRST and an != next(iter(aggressors)):
+            continue
         row = {}
         for vn, vfn in victims.items():
-            if an != next(iter(aggressors)) and vn not in ("freq_contract", "library complex mul"):
+            if (an != next(iter(aggressors)) or ONLY_FIRST) and vn not in ("freq_contract", "library complex mul", "unprojection (brick kernel, explicit v_pk)"):
                 continue
             with torch.cuda.stream(sb):
                 ref = vfn().clone()
