@@ -196,6 +196,14 @@ int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sample_of, co
                                   const float *scale, int B, int P, int V, int J, int Jp, int h, int w, int X, int Y,
                                   int Z, const float *grid_size, int W_in, int H_in, void *stream);
 int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream);
+/*
+ * Both scatters come in two kernels that give the same sums (the _det pair the same BITS): per tap (one memory atomic per
+ * 2x2 tap and 64-byte pixel), and block merge (an 8x8x4 block of voxels first adds its taps in an LDS patch, 64-bit fixed
+ * point, and every touched pixel leaves once - 3x faster where voxels lie closer than ~2 pixels, the 64^3 person cubes).
+ * The library picks by voxel pitch (<= 50 mm: merge).  which: 0 = automatic, 2 = always per tap, 3 = always merge; any
+ * other value changes nothing.  Returns the previous setting.  Process-wide; for tests and measurement.
+ */
+int sp3d_set_bwd_scatter(int which);
 
 /*
  * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,

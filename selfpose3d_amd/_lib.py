@@ -28,7 +28,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_set_bwd_scatter", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -506,6 +506,15 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
                                        _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
     check(rc, "sp3d_unproject_bwd_packed")
     return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
+
+
+def set_bwd_scatter(which: int) -> int:
+    """which kernel unproject_bwd_packed launches: 0 = by voxel pitch (default), 2 = per-tap scatter, 3 = block merge in LDS.
+    Returns the previous setting (tests and measurement; include/sp3d.h)."""
+    lib = load()
+    lib.sp3d_set_bwd_scatter.restype = C.c_int
+    lib.sp3d_set_bwd_scatter.argtypes = [C.c_int]
+    return int(lib.sp3d_set_bwd_scatter(int(which)))
 
 
 def gaussian_target_3d(roots: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor, gz: torch.Tensor, sigma: float):

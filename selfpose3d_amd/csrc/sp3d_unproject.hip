@@ -1244,6 +1244,210 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward on DENSE grids (round 4, "bwd3"): a workgroup owns an 8x8x4 block of voxels and, per view, merges the block's tap
+// gradients in an LDS patch of the heat-map gradient before they go to memory.
+//
+// What bounds the scatter (tools/global_atomic_bench.hip, profiles/r04_backward_kernels.md): memory atomics retire at
+// ~20.7 G (instruction, 64-byte segment) pairs per second chip-wide - whatever the type (f32, u32, u64, f64, packed bf16),
+// the scope, or how the segments of one instruction lie to each other; plain stores of the same segments are 4.6x
+// faster.  bwd2 issues one segment per tap (4 per voxel and view).  On the 64^3 person cubes (31.7 mm pitch, ~1.7 heat-map
+// pixels) the 1 024 taps of a block fall on ~180 distinct pixels of a ~18x12 rectangle: merged first, 4-5x fewer
+// segments leave the CU.
+// The merge cannot use fp32 LDS atomics: ds_add_f32 costs ~190 cycles per wave instruction per CU on gfx950, ds_add_u32 /
+// ds_add_u64 cost 7 (tools/lds_atomic_bench.hip).  So the patch is 64-bit FIXED POINT: tap value * 2^k, rounded to
+// nearest, with k from the block's largest |g| so that 2^50 steps span it (256 taps per pixel at most: no overflow); the
+// patch sums are exact, and one rounding to fp32 happens when a pixel leaves (bwd2 rounds after every tap).  With the
+// caller's global scale instead (DET) the flush adds the 64-bit sums to the fixed-point buffer with integer atomics:
+// bit-identical to bwd2<DET>, run to run and to each other (integer addition is associative).
+//   lane = voxel throughout (vz fastest).  gradient of the 16 channels in registers (one round trip: 16 loads in flight)
+//   pass 1: project every view -> view mask / den, rectangle of the view's 2x2 tap blocks (LDS atomicMin/Max)
+//   per view, per window of <= B3_PX pixels of the rectangle (almost always one): ds_add_u64 into patch[ch][pixel];
+//   barrier; flush-and-clear, lanes = (pixel-of-4, channel): 64-byte segments, untouched pixels are skipped.
+//   LDS: patch [JP][B3_PXS] int64 | rectangles [MAX_VIEWS][4] | block max           (49.8 KB: 3 workgroups per CU)
+// ------------------------------------------------------------------------------------------
+constexpr int B3_BX = 8, B3_BY = 8, B3_BZ = 4;
+constexpr int B3_PX = 384;       // pixels of a patch window
+constexpr int B3_PXS = 388;      // plane stride (int64 words): == 4 mod 32, so the flush's (pixel-of-4, channel) lanes spread over the banks
+#ifndef SP3D_B3_ABL
+#define SP3D_B3_ABL 0            // measurement builds only: 1 no flush atomics, 2 no tap adds, 8 no view loop, 16 no gradient loads,
+                                 // 32 no pass-1 projection, 64 no patch clear, 128 no divisions
+#endif
+
+template <int JP, bool DET>
+__global__ __launch_bounds__(256, 3) void unproject_bwd3_kernel(const float *__restrict__ cam, const float *__restrict__ centers,
+                                                            const uint8_t *__restrict__ valid,
+                                                            const float *__restrict__ grad_cubes,
+                                                            const uint16_t *__restrict__ pass_mask,
+                                                            void *__restrict__ grad_acc_, size_t view_stride, Geom g,
+                                                            int nbx, int nby, int nbz, const float *__restrict__ scale_p)
+{
+    using ACC = typename std::conditional<DET, unsigned long long, float>::type;
+    ACC *grad_acc = reinterpret_cast<ACC *>(grad_acc_);
+    extern __shared__ __attribute__((aligned(16))) unsigned long long psm3[];
+    unsigned long long *patch = psm3;                                   // [JP][B3_PXS]
+    int *rect = reinterpret_cast<int *>(patch + JP * B3_PXS);           // [MAX_VIEWS][4]: min x0, min y0, max x0 + 1, max y0 + 1
+    uint32_t *bmax = reinterpret_cast<uint32_t *>(rect + 4 * SP3D_MAX_VIEWS);
+    const int blocks_per_sample = nbx * nby * nbz;
+    int b, blk;
+    if (!xcd_map(blockIdx.x, g.B, blocks_per_sample, g.xcd_chunk, b, blk)) return;
+    if (!valid[b]) return;
+    const int bs = g.sample_of ? g.sample_of[b] : b;
+    const int tid = threadIdx.x;
+    const int bz = blk % nbz, by = (blk / nbz) % nby, bx = blk / (nbz * nby);
+    const int vx = bx * B3_BX + (tid >> 5), vy = by * B3_BY + ((tid >> 2) & 7), vz = bz * B3_BZ + (tid & 3);
+    const bool inb = vx < g.X && vy < g.Y && vz < g.Z;
+    const int n = (min(vx, g.X - 1) * g.Y + min(vy, g.Y - 1)) * g.Z + min(vz, g.Z - 1);
+    // gradient of this voxel, all channels: issued first, consumed after pass 1
+    const float *gc = grad_cubes + (size_t)b * g.J * g.N + n;
+    float gq[JP];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) gq[j] = (SP3D_B3_ABL & 16) ? (float)(j + tid) : gc[(size_t)min(j, g.J - 1) * g.N];
+    const uint32_t pm = inb ? (uint32_t)pass_mask[(size_t)b * g.N + n] : 0u;
+    if (!(SP3D_B3_ABL & 64))
+    for (int e = tid; e < JP * B3_PXS; e += 256) patch[e] = 0ull;
+    if (tid < 4 * SP3D_MAX_VIEWS) rect[tid] = (tid & 3) < 2 ? 0x7fffffff : -1;
+    if (tid == 0) *bmax = 0u;
+    __syncthreads();
+
+    const float x = linspace_step(g.Lx, g.stepx, g.X, min(vx, g.X - 1)) + centers[3 * b + 0];
+    const float y = linspace_step(g.Ly, g.stepy, g.Y, min(vy, g.Y - 1)) + centers[3 * b + 1];
+    const float z = linspace_step(g.Lz, g.stepz, g.Z, min(vz, g.Z - 1)) + centers[3 * b + 2];
+    uint32_t mymask = (SP3D_B3_ABL & 32) ? 31u : 0u;
+    for (int c = 0; c < ((SP3D_B3_ABL & 32) ? 0 : g.V); ++c) {
+        const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
+        float ix, iy;
+        bool isnan;
+        const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
+        if (bound) mymask |= (1u << c);
+        if (isnan && inb) mymask |= 0x80000000u;
+        const bool use = bound && !isnan;
+        const RecPk r = make_record_pk(use, v2f{isnan ? 0.0f : ix, isnan ? 0.0f : iy}, g.w, g.h);
+        // rectangle: reduce in the wave first (64 lanes on ONE LDS word serialise: 230 us of the kernel when every
+        // lane issued its own atomicMin/Max)
+        int lo_x = use ? r.x0 : 0x7fffffff, lo_y = use ? r.y0 : 0x7fffffff, hi_x = use ? r.x0 + 1 : -1, hi_y = use ? r.y0 + 1 : -1;
+        for (int o = 32; o > 0; o >>= 1) {
+            lo_x = min(lo_x, __shfl_xor(lo_x, o)); lo_y = min(lo_y, __shfl_xor(lo_y, o));
+            hi_x = max(hi_x, __shfl_xor(hi_x, o)); hi_y = max(hi_y, __shfl_xor(hi_y, o));
+        }
+        if ((tid & 63) == 0 && hi_x >= 0) {
+            atomicMin(&rect[4 * c + 0], lo_x); atomicMin(&rect[4 * c + 1], lo_y);
+            atomicMax(&rect[4 * c + 2], hi_x); atomicMax(&rect[4 * c + 3], hi_y);
+        }
+    }
+    // g = pass ? grad / den : 0     (autograd of project_layer.py:96-99)
+    const float den = (float)__popc(mymask & 0x7fffffffu) + 1e-6f;
+    const bool dead = (mymask & 0x80000000u) != 0 || (mymask & 0x7fffffffu) == 0;
+    uint32_t amax = 0u;
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+        float v = 0.0f;
+        if (j < g.J && inb && !dead && ((pm >> j) & 1u)) v = (SP3D_B3_ABL & 128) ? gq[j] * den : gq[j] / den;
+        gq[j] = v;
+        amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+    }
+    const bool any = amax != 0u;                       // voxels without gradient scatter nothing
+    if (!DET) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((tid & 63) == 0 && amax) atomicMax(bmax, amax);
+    }
+    __syncthreads();
+    double scale, inv_scale = 1.0;
+    bool nonfinite = false;     // uniform
+    if (DET) {
+        scale = (double)*scale_p;
+    } else {
+        const uint32_t m = *bmax;
+        if (m == 0u) return;                           // no gradient anywhere in this block (uniform)
+        if ((m >> 23) == 0xffu) {                      // Inf / NaN gradient in this block: no scale exists
+            nonfinite = true;
+            scale = 1.0;
+        } else {
+            const int k = min(50 - ((int)(m >> 23) - 126), 200);         // |g| < 2^(E - 126)  ->  |g| * 2^k < 2^50
+            scale = __longlong_as_double((long long)(k + 1023) << 52);
+            inv_scale = __longlong_as_double((long long)(1023 - k) << 52);
+        }
+    }
+    if (SP3D_B3_ABL & 8) return;
+
+    const size_t rowf = (size_t)g.w * JP;
+#pragma unroll 1
+    for (int c = 0; c < g.V; ++c) {
+        const int rx0 = rect[4 * c + 0], ry0 = rect[4 * c + 1], rx1 = rect[4 * c + 2], ry1 = rect[4 * c + 3];
+        if (rx1 < 0) continue;                          // nobody of this block sees view c (uniform)
+        const float *cm = cam + ((size_t)bs * g.V + c) * SP3D_CAM_STRIDE;
+        float ix, iy;
+        bool isnan;
+        const bool bound = sample_pos_fast(cm, x, y, z, g, ix, iy, isnan) && inb;
+        const bool use = bound && !isnan;
+        const RecPk r = make_record_pk(use, v2f{isnan ? 0.0f : ix, isnan ? 0.0f : iy}, g.w, g.h);
+        const bool act = use && any;
+        const float wts[4] = {r.wt.x, r.wt.y, r.wb.x, r.wb.y};
+        ACC *gview = grad_acc + (size_t)c * view_stride + (size_t)bs * g.h * rowf;
+        if (nonfinite) {
+            // the block holds an Inf / NaN gradient: per-tap fp32 atomics straight to memory, as bwd2 adds them (the
+            // non-finite value reaches exactly the pixels its voxel touches)
+            if constexpr (!DET) {
+                if (act) {
+                    ACC *p0 = gview + ((size_t)r.y0 * g.w + r.x0) * JP;
+#pragma unroll
+                    for (int j = 0; j < JP; ++j) {
+                        if (j >= g.J) break;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (wts[t] != 0.0f) unsafeAtomicAdd(p0 + (size_t)(t >> 1) * rowf + (t & 1) * JP + j, gq[j] * wts[t]);
+                    }
+                }
+            }
+            continue;
+        }
+        // windows of the rectangle (one, unless the block's footprint in this view is unusually large)
+        const int pw = rx1 - rx0 + 1, ph = ry1 - ry0 + 1;
+        const int ww = min(pw, B3_PX), wh = min(ph, B3_PX / ww);
+        const float rww = 1.0f / (float)ww;
+#pragma unroll 1
+        for (int wy0 = ry0; wy0 <= ry1; wy0 += wh) {
+#pragma unroll 1
+            for (int wx0 = rx0; wx0 <= rx1; wx0 += ww) {
+                if (act && !(SP3D_B3_ABL & 2)) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int tx = r.x0 + (t & 1) - wx0, ty = r.y0 + (t >> 1) - wy0;
+                        if (wts[t] == 0.0f || (unsigned)tx >= (unsigned)ww || (unsigned)ty >= (unsigned)wh) continue;
+                        unsigned long long *pp = patch + ty * ww + tx;
+                        // round-to-nearest-even of t * 2^k to int64 without a conversion sequence: the sum with 1.5 * 2^52
+                        // holds the integer in its low mantissa bits (|t * 2^k| < 2^50); taking the constant's bit
+                        // pattern off again touches only the high word.  == __double2ll_rn((double)t * scale) of bwd2<DET>.
+#pragma unroll
+                        for (int j = 0; j < JP; ++j) {
+                            if (j >= g.J) break;                                    // uniform: the pad channels carry nothing
+                            const double d = __builtin_fma((double)(gq[j] * wts[t]), scale, 6755399441055744.0);
+                            atomicAdd(pp + j * B3_PXS, (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull);
+                        }
+                    }
+                }
+                __syncthreads();
+                // flush and clear: element e = (pixel, channel), 64 lanes = 4 pixels x 16 channels = 4 segments of 64 bytes
+                const int nwx = min(ww, rx1 - wx0 + 1), nwy = min(wh, ry1 - wy0 + 1);
+                const int nel = nwy * ww * 16;
+                for (int e = tid; e < nel; e += 256) {
+                    const int px = e >> 4, ch = e & 15;
+                    if (ch >= JP) continue;
+                    const long long val = (long long)patch[ch * B3_PXS + px];
+                    if (val == 0) continue;
+                    patch[ch * B3_PXS + px] = 0ull;
+                    const int ty = (int)(((float)px + 0.5f) * rww), tx = px - ty * ww;
+                    if (tx >= nwx || (SP3D_B3_ABL & 1)) continue;
+                    ACC *dst = gview + ((size_t)(wy0 + ty) * g.w + (wx0 + tx)) * JP + ch;
+                    if constexpr (DET) atomicAdd(dst, (unsigned long long)val);
+                    else unsafeAtomicAdd(dst, (float)((double)val * inv_scale));
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long *__restrict__ acc, float *__restrict__ out,
                                                             const float *__restrict__ scale_p, size_t n)
 {
@@ -1714,6 +1918,15 @@ extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_lay
                        (hipStream_t)stream);
 }
 
+// which scatter kernel sp3d_unproject_bwd_packed[_det] launches: 0 = by voxel pitch, 2 = per-tap (bwd2), 3 = block merge (bwd3)
+static int g_bwd_scatter = 0;
+extern "C" int sp3d_set_bwd_scatter(int which)
+{
+    const int prev = g_bwd_scatter;
+    if (which == 0 || which == 2 || which == 3) g_bwd_scatter = which;
+    return prev;
+}
+
 static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
                            const float *grad_cubes, const uint16_t *pass_mask, void *grad_acc, const float *scale, int B,
                            int P, int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
@@ -1728,6 +1941,27 @@ static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const flo
     g.sample_of = sample_of;
     const int tiles = (g.N + 63) / 64;
     const size_t view_stride = (size_t)B * h * w * Jp;
+    // dense grids (the 64^3 person cubes at 31.7 mm: voxels ~1.7 heat-map pixels apart): block-wise LDS merge, bwd3.
+    // The pixel pitch depends on the cameras (device data); what the host knows is the voxel pitch in mm: <= 50 mm.
+    const bool dense = X >= 2 && Y >= 2 && Z >= 2 && (double)grid_size[0] / (X - 1) <= 50.0 &&
+                       (double)grid_size[1] / (Y - 1) <= 50.0 && (double)grid_size[2] / (Z - 1) <= 50.0;
+    if (g_bwd_scatter == 3 || (g_bwd_scatter == 0 && dense)) {
+        const int nbx = (X + B3_BX - 1) / B3_BX, nby = (Y + B3_BY - 1) / B3_BY, nbz = (Z + B3_BZ - 1) / B3_BZ;
+        const size_t lds3 = (size_t)Jp * B3_PXS * sizeof(unsigned long long) + (4 * SP3D_MAX_VIEWS + 4) * sizeof(int);
+        // the 16-byte z runs a block reads of the gradient volume share their 256-byte rows with the blocks above and
+        // below: keep a whole z column of blocks on one XCD, back to back in dispatch order (chunk = nbz when a power of two)
+        if ((nbz & (nbz - 1)) == 0) g.xcd_chunk = nbz;
+        dim3 grid3(xcd_grid_blocks(P, nbx * nby * nbz, g.xcd_chunk)), block3(256);
+        hipStream_t s3 = (hipStream_t)stream;
+#define SP3D_B3(JP_, DET_) hipLaunchKernelGGL((unproject_bwd3_kernel<JP_, DET_>), grid3, block3, lds3, s3, cam, centers, valid, grad_cubes, pass_mask, grad_acc, view_stride, g, nbx, nby, nbz, scale)
+        if (scale) {
+            switch (Jp) { case 4: SP3D_B3(4, true); break; case 8: SP3D_B3(8, true); break; case 12: SP3D_B3(12, true); break; default: SP3D_B3(16, true); break; }
+        } else {
+            switch (Jp) { case 4: SP3D_B3(4, false); break; case 8: SP3D_B3(8, false); break; case 12: SP3D_B3(12, false); break; default: SP3D_B3(16, false); break; }
+        }
+#undef SP3D_B3
+        return launch_status();
+    }
     const size_t lds = (size_t)(V * 320 + Jp * 64 + 64) * sizeof(float);
     dim3 grid(xcd_grid_blocks(P, tiles, g.xcd_chunk)), block(64);
     hipStream_t s = (hipStream_t)stream;

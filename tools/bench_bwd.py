@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from selfpose3d_amd import _lib, synthetic as syn
 from selfpose3d_amd.camera_pack import pack_cameras
+if os.environ.get("SP3D_LIB"):                      # a measurement build instead of the shipped library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SP3D_LIB"])
 dev = torch.device("cuda:0")
 def timed(fn, iters=20):
     for _ in range(3): fn()
@@ -18,6 +20,8 @@ img, (w, h), J = (960, 512), (240, 128), 15
 res = {}
 for name, B, V, cube, gs, fine in (("coarse_b2", 2, 5, syn.INITIAL_CUBE_SIZE, syn.SPACE_SIZE, False), ("coarse_b4", 4, 5, syn.INITIAL_CUBE_SIZE, syn.SPACE_SIZE, False),
                                    ("fine_p4_b2", 2, 5, syn.FINE_CUBE_SIZE, syn.FINE_GRID_SIZE, True)):
+    if os.environ.get("BWD_ONLY") and name not in os.environ["BWD_ONLY"].split(","):
+        continue
     meta = syn.make_meta(B, V, img)
     cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
     hms = [x.to(dev) for x in syn.people_heatmaps(B, V, J, h, w, img, seed=3)[0]]

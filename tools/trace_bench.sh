@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=r03
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${TAG}_trace
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o bench -- \
