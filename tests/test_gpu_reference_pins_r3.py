@@ -7,6 +7,7 @@
   * MultiPersonPoseNetSSV.forward in TRAIN mode, pose-net stage (lib/models/multi_person_posenet_ssv.py:197-501):
     every loss term and three gradients; and the drop-in entry point tools/train_3d.py on an SSV YAML.
 """
+import json
 import os
 import subprocess
 import sys
@@ -73,18 +74,42 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-@pytest.mark.parametrize("tag", ["net", "gt"])
-def test_supervised_train_step_vs_reference(dev, tag, deterministic, monkeypatch):
-    """losses <= 1e-4 relative; gradients against the reference's fp32 AND float64 runs (see below), with the scatter and
-    the deterministic unprojection backward"""
+# ---------------------------------------------------------------------------------------------------------------------
+# Training pins.  MIOpen picks a convolution's kernels from its user db when that has an entry for the shape, and another
+# test of the same run (or another process, earlier) may have left one: a different backward algorithm, a different
+# summation order - on these ill-conditioned gradients that alone moved the error against float64 between 3x and 18x the
+# reference's (round 3).  So the two train-step pins run in a CHILD process whose MIOpen user db is a fresh, empty
+# directory, in immediate mode with deterministic kernels: the library's own heuristic choice for gfx950, the same in every
+# run on every box.  The child prints its measured errors as one JSON line; the bounds below are ~3x what was measured that
+# way (profiles/r04_training_pins_measured.json, three boxes).
+# ---------------------------------------------------------------------------------------------------------------------
+def _child(args, tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT, MIOPEN_USER_DB_PATH=str(tmp_path / "miopen_user_db"))
+    env.pop("MIOPEN_FIND_MODE", None)
+    os.makedirs(env["MIOPEN_USER_DB_PATH"], exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in args], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "training_pins_measured.json")
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+    cur["_".join(str(a) for a in args[1:])] = rec
+    json.dump(cur, open(path, "w"), indent=1)
+    return rec
+
+
+def _train_step_child(tag, deterministic):
+    """losses and gradients of one supervised train step against the reference's fp32 and float64 runs -> dict"""
     from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+    dev = torch.device("cuda:0")
     g = gio.load("train_step")
-    # MIOpen picks its backward kernels by timing them (find mode) - a different algorithm, with a different summation
-    # order, from one process to the next: on this ill-conditioned gradient that alone moved the error against float64
-    # between 3x and 18x the reference's.  Immediate mode + deterministic kernels: the same algorithms every run.
-    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
-    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
     cfg = gio.train_cfg(USE_GT=(tag == "gt"))
     model = get_multi_person_pose_net(cfg, is_train=True)
     gio.he_fill(model, seed=int(g["param_seed"]))
@@ -94,55 +119,77 @@ def test_supervised_train_step_vs_reference(dev, tag, deterministic, monkeypatch
     inputs, t2d, w2d, t3d, meta, _ = gio.train_batch(cfg, B=2, seed=int(g["data_seed"]))
     inputs = [x.to(dev) for x in inputs]
     pred, hms, gc, l2d, l3d, lcord = model(views=inputs, meta=meta, targets_2d=t2d, weights_2d=w2d, targets_3d=t3d[0])
-    hm_sum = np.array([float(h.double().sum()) for h in hms])
-    assert np.allclose(hm_sum, g[f"{tag}_hm_sum"], rtol=1e-4)
+    rec = {"hm_sum_rel": float(np.abs(np.array([float(h.double().sum()) for h in hms]) / g[f"{tag}_hm_sum"] - 1.0).max())}
     for name, val in (("loss_2d", l2d), ("loss_3d", l3d), ("loss_cord", lcord)):
         ref = float(g[f"{tag}_{name}"])
-        assert abs(float(val) - ref) <= 1e-4 * max(abs(ref), 1e-6), (name, float(val), ref)
-    assert np.array_equal((gc[:, :, 3] >= 0).cpu().numpy(), g[f"{tag}_grid_centers"][:, :, 3] >= 0)
-    # Gradients.  fp32 backward passes through this net (train-mode BatchNorm over ~20 conv layers) are ill-conditioned:
-    # the REFERENCE's own fp32 gradient is 1.4 % (3D term) / 0.17 % (pose term) away from its float64 rerun, which the
-    # golden stores as the yardstick.  Pin: this repo's gradient must be about as close to the float64 one as the
-    # reference's fp32 gradient is (measured on MI355X with the fixed kernel selection above: 1.06x its error on the 3D
-    # term, 5.24x on the pose term, where MIOpen's backward kernels and the fp32 soft-argmax add their own rounding -
-    # 0.9 % of the gradient's magnitude; with find mode - and in immediate mode too, once another test of the same run has
-    # left entries in MIOpen's user db - it moved between 3x and 18x from process to process; bound: 40x = 7 % of the
-    # gradient's magnitude - a wrong gradient (a missing term, a sign) is off by O(1) = 600x), and where the problem is
-    # well conditioned (2D term, last V2V layer) match the reference to 1e-4.
-    def close_to_truth(got, name, floor=1e-4):
+        rec[name + "_rel"] = abs(float(val) - ref) / max(abs(ref), 1e-6)
+    rec["valid_equal"] = bool(np.array_equal((gc[:, :, 3] >= 0).cpu().numpy(), g[f"{tag}_grid_centers"][:, :, 3] >= 0))
+
+    def truth(got, name):           # error against the reference's float64 gradient, and the reference's own fp32 error
         ref32, ref64 = g[name], g[name + "_f64"]
         e_ref, e_got = _rel(ref32, ref64), _rel(got, ref64)
-        print(f"[{tag}] {name}: error vs float64 {e_got:.3e} (reference fp32: {e_ref:.3e}, ratio {e_got / max(e_ref, 1e-30):.2f})")
-        assert e_got <= max(40.0 * e_ref, floor), (name, e_got, e_ref)
+        rec[name] = {"err_vs_f64": e_got, "ref_fp32_err_vs_f64": e_ref, "ratio": e_got / max(e_ref, 1e-30)}
 
     fl = model.backbone.final_layer.weight
     for nm, term in (("2d", l2d), ("3d", l3d), ("cord", lcord)):
         if f"{tag}_grad_final_{nm}_f64" in g and term.requires_grad:
             gt_, = torch.autograd.grad(term.mean(), fl, retain_graph=True, allow_unused=True)
             got = np.zeros(tuple(fl.shape), np.float32) if gt_ is None else gt_.cpu().numpy()
-            close_to_truth(got, f"{tag}_grad_final_{nm}")
+            truth(got, f"{tag}_grad_final_{nm}")
     if tag == "net":
         ol = model.root_net.v2v_net.output_layer.weight
         fc = model.root_net.v2v_net.front_layers[0].block[0].weight
         ga, gb = torch.autograd.grad(l3d.mean(), (ol, fc), retain_graph=True)
-        assert _rel(ga.cpu().numpy(), g["net_grad_root_out"]) <= 1e-4          # needs only the forward pass to be right
-        close_to_truth(gb.cpu().numpy()[:, :15], "net_grad_root_front")
+        rec["net_grad_root_out_rel"] = _rel(ga.cpu().numpy(), g["net_grad_root_out"])
+        truth(gb.cpu().numpy()[:, :15], "net_grad_root_front")
     (l2d.mean() + l3d.mean() + lcord.mean()).backward()
-    close_to_truth(model.backbone.final_layer.weight.grad.cpu().numpy(), f"{tag}_grad_final")
+    truth(model.backbone.final_layer.weight.grad.cpu().numpy(), f"{tag}_grad_final")
     gp = model.pose_net.v2v_net.output_layer.weight.grad
     gp = np.zeros_like(g[f"{tag}_grad_pose_out"]) if gp is None else gp.cpu().numpy()
     if np.abs(g[f"{tag}_grad_pose_out"]).max() > 0:
-        # (a fixed 2e-3 against the reference's fp32 gradient held on most boxes and failed at 2.5e-3 on one: MIOpen's
-        # kernel choice moves it; the float64 yardstick is the honest bound here too)
-        close_to_truth(gp, f"{tag}_grad_pose_out")
+        truth(gp, f"{tag}_grad_pose_out")
     else:
-        assert np.abs(gp).max() == 0.0                  # pose net not reached: zero-anchored, exactly zero gradient
+        rec["pose_out_grad_absmax"] = float(np.abs(gp).max())
+    return rec
 
 
-def test_ssv_train_step_vs_reference(dev, monkeypatch):
+# error against float64 as a multiple of the reference's own fp32 error against float64 (its gradient is 1.4 % (3D term) /
+# 0.17 % (pose term) away from its float64 rerun: fp32 backward through train-mode BatchNorm over ~20 conv layers is
+# ill-conditioned); bounds = ~3x the largest value measured with the pinned kernel selection, see above.  A wrong gradient
+# (a missing term, a sign) is off by O(1) = 70x .. 600x.
+GRAD_RATIO_BOUND = {"net_grad_final_2d": 3.0, "net_grad_final_3d": 3.2, "net_grad_final": 3.2, "net_grad_root_front": 2.5,   # measured 0.81 1.06 1.06 0.75
+                    "gt_grad_final_2d": 3.0, "gt_grad_final_cord": 16.0, "gt_grad_final": 16.0, "gt_grad_pose_out": 8.0}     # measured 0.81 5.24 5.24 2.1-2.7
+GRAD_FLOOR = 1e-4          # where the problem is well conditioned both errors are ~1e-6: a ratio means nothing below this
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("tag", ["net", "gt"])
+def test_supervised_train_step_vs_reference(dev, tag, deterministic, tmp_path):
+    """losses <= 1e-4 relative; gradients against the reference's fp32 AND float64 runs, with the scatter and the
+    deterministic unprojection backward"""
+    rec = _child(["--train-step-child", tag, int(deterministic)], tmp_path)
+    print(json.dumps(rec))
+    assert rec["hm_sum_rel"] <= 1e-4 and rec["valid_equal"]
+    for name in ("loss_2d", "loss_3d", "loss_cord"):
+        assert rec[name + "_rel"] <= 1e-4, (name, rec)
+    if tag == "net":
+        assert rec["net_grad_root_out_rel"] <= 1e-4               # needs only the forward pass to be right
+    seen = 0
+    for key, v in rec.items():
+        if isinstance(v, dict):
+            bound = GRAD_RATIO_BOUND[key]
+            assert v["err_vs_f64"] <= max(bound * v["ref_fp32_err_vs_f64"], GRAD_FLOOR), (key, v, bound)
+            seen += 1
+    assert seen >= 3
+    if "pose_out_grad_absmax" in rec:
+        assert rec["pose_out_grad_absmax"] == 0.0           # pose net not reached: zero-anchored, exactly zero gradient
+
+
+def _ssv_step_child():
     from selfpose3d_amd.models import get_multi_person_pose_net
-    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)       # same MIOpen kernels every run (see above)
-    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
     g = gio.load("ssv_train_step")
     cfg = gio.train_cfg(ssv=True)
     model = get_multi_person_pose_net(cfg, is_train=True)
@@ -156,23 +203,37 @@ def test_ssv_train_step_vs_reference(dev, monkeypatch):
                                   views2=in2, meta2=m2, targets_2d2=t2, weights_2d2=w2, targets_3d2=d2[0],
                                   views3=in3, meta3=m3, targets_2d3=t3, weights_2d3=w3, targets_3d3=d3[0],
                                   epoch=int(g["epoch"]))
-    assert sorted(losses) == [str(k) for k in g["keys"]]
-    assert np.array_equal((gc[:, :, 3] >= 0).cpu().numpy(), g["grid_centers"][:, :, 3] >= 0)
+    rec = {"keys_equal": sorted(losses) == [str(k) for k in g["keys"]],
+           "valid_equal": bool(np.array_equal((gc[:, :, 3] >= 0).cpu().numpy(), g["grid_centers"][:, :, 3] >= 0)), "loss_rel": {}}
     for k, v in losses.items():
         ref = float(g["loss_" + k])
-        assert abs(float(v.mean()) - ref) <= 2e-4 * max(abs(ref), 1e-6), (k, float(v.mean()), ref)
-    # predicted joints of the second augmented pass (mm)
+        rec["loss_rel"][k] = abs(float(v.mean()) - ref) / max(abs(ref), 1e-6)
     ok = g["grid_centers"][:, :, 3] >= 0
-    # mm, on 2000 mm cubes of 62.5 mm voxels: the soft-argmax of a random-weight pose net amplifies the library convolutions'
-    # rounding (measured 0.2-1.6 mm depending on MIOpen's kernel choice); a wrong cube or joint is off by >= a voxel
-    assert np.abs(pred.cpu().numpy()[ok][..., :3] - g["pred"][ok][..., :3]).max() <= 5.0
+    rec["joints_mm"] = float(np.abs(pred.cpu().numpy()[ok][..., :3] - g["pred"][ok][..., :3]).max())
     sum(v.mean() for v in losses.values() if v.requires_grad).backward()
     for nm, got in (("grad_final", model.backbone.final_layer.weight.grad),
                     ("grad_pose_out", model.pose_net.v2v_net.output_layer.weight.grad),
                     ("grad_attn_final", model.attn.backbone.final_layer.weight.grad)):
-        e = _rel(got.cpu().numpy(), g[nm])
-        print(f"[ssv] {nm}: {e:.3e} from the reference's fp32 gradient")
-        assert e <= 2e-2, (nm, e)       # measured 7e-5 .. 1.3e-3; the library's kernel choice moves it (see above); wrong = O(1)
+        rec[nm] = _rel(got.cpu().numpy(), g[nm])
+    return rec
+
+
+# SSV step: joints in mm on 2000 mm cubes of 62.5 mm voxels (the soft-argmax of a random-weight pose net amplifies the
+# library convolutions' rounding; a wrong cube or joint is off by >= a voxel), gradients relative to the reference's fp32
+# gradient; ~3x the largest value measured with the pinned kernel selection.
+SSV_JOINTS_MM = 3.0                                                                  # measured 0.97
+SSV_GRAD_REL = {"grad_final": 5e-3, "grad_pose_out": 4e-3, "grad_attn_final": 2.5e-4}     # measured 1.6e-3, 1.3e-3, 6.8e-5
+
+
+def test_ssv_train_step_vs_reference(dev, tmp_path):
+    rec = _child(["--ssv-step-child"], tmp_path)
+    print(json.dumps(rec))
+    assert rec["keys_equal"] and rec["valid_equal"]
+    for k, e in rec["loss_rel"].items():
+        assert e <= 2e-4, (k, e)
+    assert rec["joints_mm"] <= SSV_JOINTS_MM, rec
+    for nm, bound in SSV_GRAD_REL.items():
+        assert rec[nm] <= bound, (nm, rec[nm], bound)       # a wrong gradient is off by O(1)
 
 
 def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
@@ -184,3 +245,11 @@ def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
                        cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "loss_pose3d_ssv" in r.stderr + r.stdout
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    if sys.argv[1] == "--train-step-child":
+        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])))))
+    elif sys.argv[1] == "--ssv-step-child":
+        print(json.dumps(_ssv_step_child()))
