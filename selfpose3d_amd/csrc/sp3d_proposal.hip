@@ -113,11 +113,21 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float
     const int x0 = tx * NT_X, y0 = ty * NT_Y, z0 = tz * NT_Z;
     const float *c = cubes + (size_t)b * X * Y * Z;
     const float ninf = -INFINITY;
-    for (int e = threadIdx.x; e < HX * HY * HZ; e += NMS_THREADS) {
+    // all loads of the thread first, then the LDS stores: one memory round trip instead of one per iteration (16.3 -> 11.6 us)
+    constexpr int NLOAD = (HX * HY * HZ + NMS_THREADS - 1) / NMS_THREADS;
+    float ld[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int e = i * NMS_THREADS + threadIdx.x;
         const int hz = e % HZ, r = e / HZ, hy = r % HY, hx = r / HY;
         const int x = x0 + hx - 1, y = y0 + hy - 1, z = z0 + hz - 1;
-        const bool in = (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
-        sa[e] = in ? c[((size_t)x * Y + y) * Z + z] : ninf;
+        const bool in = e < HX * HY * HZ && (unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z;
+        ld[i] = in ? c[((size_t)x * Y + y) * Z + z] : ninf;
+    }
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int e = i * NMS_THREADS + threadIdx.x;
+        if (e < HX * HY * HZ) sa[e] = ld[i];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < HX * HY * NT_Z; e += NMS_THREADS) {
@@ -176,6 +186,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_chunk_topk_kernel(const float
     }
 }
 
+// (Round 4 tried ONE launch - the last tile of a sample to arrive at an atomicInc ticket runs stage 2 in place: bit-equal,
+// but 25.3 us against 11.6 + 10.7 us for the two kernels back to back.  Every tile pays an agent-scope release fence (an L2
+// write-back) to publish eight candidates across XCDs, and the queued second launch already starts ~2 us after the first
+// drains.  Not shipped; profiles/r04_nms_one_launch.md.)
 // stage 2: one workgroup per sample merges nchunks*k candidates (per-wave top-k over a strided share held in registers,
 // then wave 0 merges the four lists), and lanes 0..k-1 unravel their winner and convert it to mm in parallel.
 // Candidate sets beyond NMS_THREADS * MERGE_PER_THREAD are reduced in passes of that size (carry = the running top-k).

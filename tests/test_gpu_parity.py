@@ -245,6 +245,39 @@ def test_nms_topk(dev):
     assert torch.count_nonzero(vals) == 0
 
 
+def test_nms_batches_merge_passes_and_graph_replay(dev):
+    """several samples, a volume whose candidates need several merge passes, k = 32, many tiny samples, repeated calls, and
+    replay from a HIP graph - all bit-equal to the oracle"""
+    from oracle import oracle
+    from selfpose3d_amd import _lib
+    rng = np.random.default_rng(11)
+    for shape, k in (((3, 80, 80, 20), 10), ((2, 160, 160, 40), 10), ((1, 13, 9, 70), 32), ((260, 8, 8, 4), 5)):
+        x = rng.random(shape, dtype=np.float32)
+        x[x < 0.7] = 0.0
+        rv, ri = oracle.nms_topk(x, k)
+        xd = torch.from_numpy(x).to(dev)
+        for _ in range(3):
+            vals, idx, _ = _lib.nms_topk(xd, k)
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv), shape
+    x = rng.random((2, 80, 80, 20), dtype=np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    ref = _lib.nms_proposals(xd, 10, [8000.0, 8000.0, 2000.0], [0.0, -500.0, 800.0], 0.3).clone()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        _lib.nms_proposals(xd, 10, [8000.0, 8000.0, 2000.0], [0.0, -500.0, 800.0], 0.3)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            out = _lib.nms_proposals(xd, 10, [8000.0, 8000.0, 2000.0], [0.0, -500.0, 800.0], 0.3)
+    for _ in range(5):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    rv, ri = oracle.nms_topk(x, 10)
+    assert np.array_equal(out[:, :, 4].cpu().numpy(), rv)
+
+
 def test_soft_argmax(dev):
     from oracle import oracle
     from selfpose3d_amd import _lib
