@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(256, 3) void unproject_bwd3_kernel(const float *__r
                         // pattern off again touches only the high word.  == __double2ll_rn((double)t * scale) of bwd2<DET>.
 #pragma unroll
                         for (int j = 0; j < JP; ++j) {
-                            if (j >= g.J) break;                                    // uniform: the pad channels carry nothing
+                            if (j >= g.J) break;                                    // uniform: the pad channels carry nothing (testing only the last three is 5 % slower)
                             const double d = __builtin_fma((double)(gq[j] * wts[t]), scale, 6755399441055744.0);
                             atomicAdd(pp + j * B3_PXS, (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull);
                         }
