@@ -471,8 +471,9 @@ def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual
 
 def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mask: torch.Tensor, batch: int,
                          num_views: int, J: int, jp: int, h: int, w: int, cube_size, grid_size, img_size,
-                         sample_of: Optional[torch.Tensor] = None, deterministic: bool = False):
-    """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer.
+                         sample_of: Optional[torch.Tensor] = None, deterministic: bool = False, return_packed: bool = False):
+    """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer
+    (``return_packed``: that buffer itself, pad channels zero).
     ``deterministic``: accumulate in 64-bit fixed point (integer atomics): bit-identical run to run."""
     lib = load()
     dev = cam.device
@@ -498,14 +499,14 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
         packed = torch.empty((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
         check(lib.sp3d_fixed_to_float(fixed.data_ptr(), packed.data_ptr(), scale.data_ptr(), fixed.numel(), _stream(dev)),
               "sp3d_fixed_to_float")
-        return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
+        return packed if return_packed else [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
     packed = torch.zeros((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
     rc = lib.sp3d_unproject_bwd_packed(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                        centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),
                                        packed.data_ptr(), int(batch), P, num_views, J, jp, h, w, X, Y, Z,
                                        _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
     check(rc, "sp3d_unproject_bwd_packed")
-    return [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
+    return packed if return_packed else [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
 
 
 def set_bwd_scatter(which: int) -> int:

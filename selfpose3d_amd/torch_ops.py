@@ -9,7 +9,8 @@ restatement under ``oracle/`` is test infrastructure).
       cam  (B,V,64) fp32 table of include/sp3d.h (camera_pack.pack_cameras)
       centers (B,3) fp32 mm, valid (B,) uint8 (0 = skipped row, written as zeros, project_layer.py:54)
   unproject_bwd(grad_cubes, hm, cam, centers, valid, grid_size, cube_size, img_size, hm_size, joints=-1)
-      -> grad_hm, same shape/layout as hm             autograd of the above w.r.t. the heat-maps
+      -> grad_hm, same shape/layout as hm             autograd of the above w.r.t. the heat-maps (J <= 16: pass-mask forward +
+                                                      the packed scatter of the C ABI's training pair; else the planar scatter)
 Autograd is registered, so ``unproject_fwd`` is differentiable in ``hm`` (grids carry no gradient, as in the reference).
 """
 from typing import Sequence, Tuple
@@ -64,11 +65,29 @@ def unproject_bwd(grad_cubes: torch.Tensor, hm: torch.Tensor, cam: torch.Tensor,
                   valid: torch.Tensor, grid_size: Sequence[float], cube_size: Sequence[int], img_size: Sequence[int],
                   hm_size: Sequence[int], joints: int = -1) -> torch.Tensor:
     layout, jp, J = _layout(hm, hm_size, joints)
-    V = int(hm.shape[0])
+    V, B = int(hm.shape[0]), int(hm.shape[1])
+    w, h = int(hm_size[0]), int(hm_size[1])
+    camf, cen, val = cam.contiguous().float(), centers.contiguous().float(), valid.contiguous().to(torch.uint8)
+    if J <= 16 and w >= 2 and h >= 2:
+        # the training pair of the C ABI (include/sp3d.h): one forward pass over channels-last maps for the clamp pass mask,
+        # then the line-coalesced / block-merge scatter - 10-50x faster than the planar scatter below, same sums
+        if layout == _lib.LAYOUT_NHWC:
+            packed = hm.contiguous().float()
+        else:
+            jp = (J + 3) // 4 * 4
+            packed = _lib.pack_heatmaps([hm[c] for c in range(V)], jp=jp)
+        X, Y, Z = (int(c) for c in cube_size)
+        mask = torch.empty((B, X * Y * Z), dtype=torch.int16, device=hm.device)
+        _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, jp, camf, cen, val, B, J, h, w, cube_size, grid_size,
+                           img_size, False, pass_mask=mask)
+        g = _lib.unproject_bwd_packed(camf, cen, val, grad_cubes, mask, B, V, J, jp, h, w, cube_size, grid_size, img_size,
+                                      return_packed=True)                  # (V,B,h,w,jp), pad channels zero
+        if layout == _lib.LAYOUT_NHWC:
+            return g
+        return g[..., :J].permute(0, 1, 4, 2, 3).contiguous()
     planar = hm if layout == _lib.LAYOUT_PLANAR else hm[..., :J].permute(0, 1, 4, 2, 3)
     planar = planar.contiguous().float()
-    g = _lib.unproject_bwd([planar[c] for c in range(V)], cam.contiguous().float(), centers.contiguous().float(),
-                           valid.contiguous().to(torch.uint8), grad_cubes, cube_size, grid_size, img_size)
+    g = _lib.unproject_bwd([planar[c] for c in range(V)], camf, cen, val, grad_cubes, cube_size, grid_size, img_size)
     g = torch.stack(list(g), 0)                                            # (V,B,J,h,w)
     if layout == _lib.LAYOUT_PLANAR:
         return g

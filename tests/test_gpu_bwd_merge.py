@@ -132,3 +132,25 @@ def test_block_merge_scatter_zero_and_nonfinite_gradients(dev):
     assert torch.equal(bad3, bad2) and 0 < int(bad3.sum()) <= 5 * 4      # the 2x2 taps of one voxel in each view, channel 2
     ok = ~bad3
     assert (got[ok] - base[ok]).abs().max() <= 1e-4 * base.abs().max()
+
+
+@pytest.mark.parametrize("layout", ["planar", "nhwc"])
+def test_registered_op_backward_takes_the_fast_scatter(dev, layout):
+    """torch.ops.selfpose3d_mi.unproject_bwd with J <= 16 = pass-mask forward + packed scatter (here: the block merge, a
+    dense grid): the same gradient as the first-generation planar scatter it used to call, in both input layouts"""
+    import selfpose3d_amd.torch_ops  # noqa: F401
+    from selfpose3d_amd import _lib
+    cube, grid_size, hm, J, jp = CASES["person_cube_ragged"]
+    d, mask, hms, cam_np, centers, valid, wgt = _setup(dev, cube, grid_size, hm, J, jp, seed=21)
+    hmd = [x.to(dev) for x in hms]
+    ref = torch.stack(_lib.unproject_bwd(hmd, d["cam"], d["cen"], d["val"], d["wgt"], list(cube), list(grid_size), IMG))
+    inp = torch.stack(hmd, 0) if layout == "planar" else _lib.pack_heatmaps(hmd, jp=16)
+    got = torch.ops.selfpose3d_mi.unproject_bwd(d["wgt"], inp, d["cam"], d["cen"], d["val"], list(grid_size), list(cube),
+                                                list(IMG), list(hm), J)
+    assert got.shape == inp.shape
+    if layout == "nhwc":
+        assert float(got[..., J:].abs().max()) == 0.0
+        got = got[..., :J].permute(0, 1, 4, 2, 3)
+    for j in range(J):
+        scale = float(ref[:, :, j].abs().max())
+        assert float((got[:, :, j] - ref[:, :, j]).abs().max()) <= 2e-5 * scale, j
