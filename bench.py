@@ -67,7 +67,7 @@ def parse():
                     help="leave library-GEMM selection to the rocBLAS/hipBLASLt heuristics (default: opt in to TunableOp "
                          "for the inference plan's GEMMs, V2VNet.tune_gemms(True); recorded in config.gemm_selection)")
     ap.add_argument("--legs", default="auto",
-                    help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, unprojection_grids, or 'auto' "
+                    help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, unprojection_grids, unprojection_backward, or 'auto' "
                          "(all four: train_step = BASELINE configs[2], at every N) or 'none'")
     ap.add_argument("--share-gpu", action="store_true",
                     help="smoke mode for boxes with ONE GPU: every rank uses cuda:0 and the process group is gloo (the whole "
@@ -514,6 +514,77 @@ def unprojection_grids_leg(dev, iters=100):
     return out
 
 
+ATOMIC_SEGMENT_RATE_G = 20.7      # memory atomics: G (instruction, 64-byte segment) pairs per second, profiles/r04_backward_kernels.md
+
+
+def unprojection_backward_leg(dev, iters=30):
+    """The backward scatter of the unprojection (autograd of lib/models/project_layer.py:93-99 w.r.t. the heat-maps) on the
+    grids of the train step (BASELINE configs[2]): root grid 80x80x20 of B = 4 frames (per-tap scatter) and four 64^3 person
+    cubes of 2 frames (block merge in LDS), fp32 atomics and the deterministic 64-bit fixed-point form.  HIP events around
+    the binding's call (zero-fill of the gradient buffer included).  Two yardsticks: SURVEY 8(d)'s algorithmic bytes against
+    8 TB/s, and the memory-atomic request rate measured on this chip (a scatter's own roofline: one slot per instruction and
+    64-byte segment).  Check: the two scatter kernels agree bit for bit in the deterministic form on the person cubes, and
+    the fp32 form is within 2e-6 of it."""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.camera_pack import pack_cameras
+    img, (w, h), J = (960, 512), (240, 128), 15
+    out = {}
+    for name, B, cube, gs, fine in (("root_grid_b4", 4, syn.INITIAL_CUBE_SIZE, syn.SPACE_SIZE, False),
+                                    ("four_64cubes_b2", 2, syn.FINE_CUBE_SIZE, syn.FINE_GRID_SIZE, True)):
+        V = 5
+        N = cube[0] * cube[1] * cube[2]
+        meta = syn.make_meta(B, V, img)
+        cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
+        hms = [x.to(dev) for x in syn.people_heatmaps(B, V, J, h, w, img, seed=3)[0]]
+        if fine:
+            P = 4
+            rng = np.random.default_rng(0)
+            c = np.stack([rng.uniform(-1500, 1500, P), rng.uniform(-2000, 1000, P), rng.uniform(700, 1100, P)], 1).astype(np.float32)
+            centers = torch.from_numpy(c).to(dev)
+            sample_of = torch.tensor([0, 0, 1, 1], dtype=torch.int32, device=dev)
+        else:
+            P = B
+            centers = torch.tensor([syn.SPACE_CENTER] * B, dtype=torch.float32, device=dev)
+            sample_of = None
+        valid = torch.ones(P, dtype=torch.uint8, device=dev)
+        g = torch.randn(P, J, *cube, device=dev)
+        packed = _lib.pack_heatmaps(hms, jp=16)
+        mask = torch.empty((P, N), dtype=torch.int16, device=dev)
+        _lib.unproject_fwd([packed[i] for i in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, P, J, h, w, cube, gs, img,
+                           False, sample_of=sample_of, pass_mask=mask)
+
+        def run(det=False):
+            return _lib.unproject_bwd_packed(cam, centers, valid, g, mask, B, V, J, 16, h, w, cube, gs, img, sample_of=sample_of,
+                                             deterministic=det, return_packed=True)
+        t = float(np.median([event_time_ms(run, iters, dev) for _ in range(3)]))
+        td = float(np.median([event_time_ms(lambda: run(True), iters, dev) for _ in range(3)]))
+        alg = 4.0 * (P * J * N + 2 * V * B * J * h * w)           # gradient cubes read + gradient maps read-modify-write
+        rec = {"us": round(t * 1e3, 1), "deterministic_us": round(td * 1e3, 1), "algorithmic_bytes": int(alg),
+               "frac_hbm": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "kernel": "unproject_bwd3_kernel (8x8x4 voxel blocks merged in LDS, 64-bit fixed point)" if fine else
+                         "unproject_bwd2_kernel (one memory atomic per tap and 64-byte pixel)"}
+        out[name] = rec
+        if fine:
+            prev = _lib.set_bwd_scatter(2)
+            try:
+                d2 = run(True)
+                t2 = float(np.median([event_time_ms(run, iters, dev) for _ in range(3)]))
+            finally:
+                _lib.set_bwd_scatter(prev)
+            d3, f3 = run(True), run(False)
+            scale = float(d3.abs().max())
+            rec["per_tap_kernel_us"] = round(t2 * 1e3, 1)
+            rec["output_check"] = {"ok": bool(torch.equal(d2, d3)) and float((f3 - d3).abs().max()) <= 2e-6 * scale,
+                                   "deterministic_merge_equals_per_tap_bitwise": bool(torch.equal(d2, d3)),
+                                   "fp32_vs_fixed_point_max_rel": float((f3 - d3).abs().max()) / max(scale, 1e-30)}
+    out["request_rate_model"] = {"G_segment_adds_per_s": ATOMIC_SEGMENT_RATE_G,
+                                 "what": ("memory atomics retire at ~20.7 G (instruction, 64-byte segment) pairs per second on MI355X "
+                                          "whatever type, scope or pattern (tools/global_atomic_bench.hip); the per-tap kernel on the root "
+                                          "grid runs at that rate (5.7 M segments), the merge kernel leaves 3.06 M segments for the person "
+                                          "cubes instead of ~19 M (TCC_ATOMIC, profiles/r04_pmc_bwd_fine.json)")}
+    return out
+
+
 def unprojection_grids_check(dev, tol=1e-6):
     """the kernels this leg times, on the inputs of the reference goldens of the same grids (reference ProjectLayer.get_voxel,
     tests/golden/make_goldens.py): configs[3] = unproj_stress_v10 (10 views -> 160x160x40), configs[2]/[4] cube =
@@ -688,7 +759,7 @@ def main():
     cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
                                                    not args.no_winograd, args.planar_input, not args.no_gemm_tuning)
     legs = args.legs.split(",") if args.legs not in ("auto", "none") else \
-        ([] if args.legs == "none" else ["pose_stage", "planar_handover", "unprojection_grids", "train_step"])
+        ([] if args.legs == "none" else ["pose_stage", "planar_handover", "unprojection_grids", "unprojection_backward", "train_step"])
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
@@ -846,6 +917,11 @@ def main():
                 extra["unprojection_grids"] = unprojection_grids_leg(dev)
             except Exception as e:
                 extra["unprojection_grids"] = {"error": f"{type(e).__name__}: {e}"}
+        if "unprojection_backward" in legs:
+            try:
+                extra["unprojection_backward"] = unprojection_backward_leg(dev)
+            except Exception as e:
+                extra["unprojection_backward"] = {"error": f"{type(e).__name__}: {e}"}
         result["legs"] = extra
         print(json.dumps(result), flush=True)
         if "output_check" in result and not result["output_check"]["ok"] and not args.share_gpu:
