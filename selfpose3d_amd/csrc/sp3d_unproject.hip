@@ -1264,18 +1264,21 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
 //   pass 1: project every view -> view mask / den, rectangle of the view's 2x2 tap blocks (LDS atomicMin/Max)
 //   per view, per window of <= B3_PX pixels of the rectangle (almost always one): ds_add_u64 into patch[ch][pixel];
 //   barrier; flush-and-clear, lanes = (pixel-of-4, channel): 64-byte segments, untouched pixels are skipped.
-//   LDS: patch [JP][B3_PXS] int64 | rectangles [MAX_VIEWS][4] | block max           (49.8 KB: 3 workgroups per CU)
+//   LDS: patch [JP][B3_PXS] int64 | rectangles [MAX_VIEWS][4] | block max           (33.5 KB: 4 workgroups per CU)
 // ------------------------------------------------------------------------------------------
 constexpr int B3_BX = 8, B3_BY = 8, B3_BZ = 4;
-constexpr int B3_PX = 384;       // pixels of a patch window
-constexpr int B3_PXS = 388;      // plane stride (int64 words): == 4 mod 32, so the flush's (pixel-of-4, channel) lanes spread over the banks
+#ifndef SP3D_B3_PX
+#define SP3D_B3_PX 256        // A/B on one box, us fp32 / deterministic: 128: 300 / 352, 192: 268 / 350, 256: 274 / 330, 384: 289 / 327, 512: 354 / 346
+#endif
+constexpr int B3_PX = SP3D_B3_PX;    // pixels of a patch window (a multiple of 32)
+constexpr int B3_PXS = B3_PX + 4;    // plane stride (int64 words): == 4 mod 32, so the flush's (pixel-of-4, channel) lanes spread over the banks
 #ifndef SP3D_B3_ABL
 #define SP3D_B3_ABL 0            // measurement builds only: 1 no flush atomics, 2 no tap adds, 8 no view loop, 16 no gradient loads,
                                  // 32 no pass-1 projection, 64 no patch clear, 128 no divisions
 #endif
 
 template <int JP, bool DET>
-__global__ __launch_bounds__(256, 3) void unproject_bwd3_kernel(const float *__restrict__ cam, const float *__restrict__ centers,
+__global__ __launch_bounds__(256, 4) void unproject_bwd3_kernel(const float *__restrict__ cam, const float *__restrict__ centers,
                                                             const uint8_t *__restrict__ valid,
                                                             const float *__restrict__ grad_cubes,
                                                             const uint16_t *__restrict__ pass_mask,
