@@ -38,7 +38,7 @@ class MultiPersonPoseNet(nn.Module):
             self.root_net.use_channels_last(on)
             self.pose_net.use_channels_last(on)
         if self.backbone is not None:
-            self.backbone.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+            pose_resnet.set_backbone_memory_format(self.backbone, on)
         return self
 
     def heatmaps(self, views, input_heatmaps):

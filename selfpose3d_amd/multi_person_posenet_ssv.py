@@ -70,7 +70,7 @@ class MultiPersonPoseNetSSV(nn.Module):
                 getattr(self, name).use_channels_last(on)
         for net in (self.backbone, getattr(self, "attn", None)):
             if net is not None:
-                net.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+                pose_resnet.set_backbone_memory_format(net, on)
         return self
 
     def _heatmaps(self, views, input_heatmaps):

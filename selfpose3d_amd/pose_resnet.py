@@ -3,7 +3,8 @@ PyTorch-ROCm module.  Architecture and ``state_dict`` keys follow the reference'
 /root/reference/lib/models/pose_resnet.py:96-262 (``conv1 bn1 layer1..4 deconv_layers.{0,1,3,4,6,7}
 final_layer``) so ``pose_resnet50_panoptic.pth.tar`` loads unchanged.  north_star keeps this network
 on the framework's conv kernels; what is MI355X-specific here is ``forward_views``: all V camera
-views go through the network as ONE (V*B) batch in channels_last.
+views go through the network as ONE (V*B) batch - in channels_last in eval mode, and in train mode with BatchNorm
+statistics kept per view (``ViewBatchNorm2d``), so the result is the reference's per-view loop's.
 """
 from __future__ import annotations
 
@@ -16,8 +17,50 @@ import torch.nn.functional as F
 _BN_MOM = 0.1
 
 
+_COEF = {}
+
+
+def _view_coefficients(V: int, m: float, dtype, device) -> torch.Tensor:
+    """weights of V sequential momentum-m updates of a running statistic (view 0 first), built once per device: a fresh
+    torch.tensor(..., device=cuda) is a synchronous host-to-device copy in every BatchNorm layer of every step"""
+    key = (V, m, dtype, str(device))
+    if key not in _COEF:
+        _COEF[key] = torch.tensor([m * (1.0 - m) ** (V - 1 - v) for v in range(V)], dtype=dtype, device=device)
+    return _COEF[key]
+
+
+class ViewBatchNorm2d(nn.BatchNorm2d):
+    """BatchNorm2d that, in TRAIN mode with ``views = V > 1``, normalises an (B*V, C, H, W) batch stacked sample-major
+    (image n = b*V + v) with the statistics of EACH VIEW's B images separately - what the reference's per-view loop
+    (`lib/models/multi_person_posenet.py:44-47`: one backbone call per camera) computes - in one pass: the contiguous batch
+    viewed as (B, V*C, H, W) is a plain BatchNorm over V*C channels.  The running statistics receive the V sequential
+    momentum updates of the loop (view 0 first) in closed form.  Same parameters, buffers and state_dict keys as BatchNorm2d;
+    with ``views == 1`` or in eval mode it IS BatchNorm2d."""
+    views = 1
+
+    def forward(self, x):
+        V = self.views
+        if V <= 1 or not self.training:
+            return super().forward(x)
+        N, C, H, W = x.shape
+        if N % V or self.momentum is None or not self.track_running_stats:
+            raise ValueError("ViewBatchNorm2d: batch must hold V views of every sample; momentum must be a number")
+        x = x.contiguous()
+        mean = x.new_zeros(V * C)
+        var = x.new_ones(V * C)
+        y = F.batch_norm(x.view(N // V, V * C, H, W), mean, var, self.weight.repeat(V), self.bias.repeat(V), True, 1.0, self.eps)
+        with torch.no_grad():       # momentum 1.0 left the batch mean / unbiased variance of every (view, channel) in the buffers
+            m = float(self.momentum)
+            coef = _view_coefficients(V, m, mean.dtype, mean.device)
+            keep = (1.0 - m) ** V
+            self.running_mean.mul_(keep).add_(coef @ mean.view(V, C))
+            self.running_var.mul_(keep).add_(coef @ var.view(V, C))
+            self.num_batches_tracked += V
+        return torch.ops.aten._unsafe_view(y, (N, C, H, W))     # not an autograd view: the in-place ReLU behind it needs no CopySlices
+
+
 def _bn2(c):
-    return nn.BatchNorm2d(c, momentum=_BN_MOM)
+    return ViewBatchNorm2d(c, momentum=_BN_MOM)
 
 
 class BasicBlock(nn.Module):
@@ -63,6 +106,8 @@ _SPEC = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bo
 
 
 class PoseResNet(nn.Module):
+    batch_views_in_training = True      # forward_views in train mode: one pass with per-view BatchNorm statistics (False: V calls)
+
     def __init__(self, cfg, num_layers=None):
         super().__init__()
         block, depths = _SPEC[int(cfg.POSE_RESNET.NUM_LAYERS if num_layers is None else num_layers)]
@@ -122,9 +167,28 @@ class PoseResNet(nn.Module):
         On the GPU the 1x1 head runs with its filter bank zero-padded to ceil4(J) outputs in channels_last, so its
         result IS the (V,B,h,w,Jp) buffer the unprojection kernel gathers from; the returned per-view tensors are
         (B,J,h,w) views of it (``project_layer.nhwc_heatmap_views``) and the re-tiling pass disappears."""
-        if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
-            return [self.forward(v) for v in views]
         V, B = len(views), views[0].shape[0]
+        if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+            # weights in channels_last make every convolution emit channels_last, which the (B, V*C, H, W) view of
+            # ViewBatchNorm2d cannot address: such a backbone keeps the per-view loop (MultiPersonPoseNet.use_channels_last
+            # leaves a training backbone in the plain format)
+            if (not self.batch_views_in_training or V == 1 or not views[0].is_cuda or
+                    not self.conv1.weight.is_contiguous()):
+                return [self.forward(v) for v in views]
+            # one pass over all views with per-view BatchNorm statistics (ViewBatchNorm2d): the V x fewer, V x larger
+            # kernels of the same arithmetic; gradients of the shared weights need no accumulation across calls
+            bns = [m for m in self.modules() if isinstance(m, ViewBatchNorm2d)]
+            for m in bns:
+                m.views = V
+            try:
+                # image n = b * V + v, plain NCHW: the (B, V*C, H, W) view of ViewBatchNorm2d needs it (frames that arrive with
+                # channels-last strides would make every convolution emit channels-last and every BatchNorm copy)
+                y = self.forward(torch.stack(list(views), 1).flatten(0, 1).contiguous(memory_format=torch.contiguous_format))
+            finally:
+                for m in bns:
+                    m.views = 1
+            y = y.view(B, V, *y.shape[1:])
+            return [y[:, v] for v in range(V)]
         x = torch.cat(list(views), 0).contiguous(memory_format=torch.channels_last)
         fl = self.final_layer
         J = fl.out_channels
@@ -141,6 +205,13 @@ class PoseResNet(nn.Module):
         y = F.conv2d(feat, wgt, bias, fl.stride, fl.padding).contiguous(memory_format=torch.channels_last)
         packed = y.permute(0, 2, 3, 1).view(V, B, y.shape[2], y.shape[3], jp)
         return nhwc_heatmap_views(packed, J)
+
+
+def set_backbone_memory_format(net: nn.Module, channels_last: bool) -> nn.Module:
+    """channels_last weights for a backbone (what MIOpen's NHWC kernels want) - except for a PoseResNet that is in train mode
+    and batches its views (``forward_views`` + ViewBatchNorm2d need the plain format)"""
+    batched_training = isinstance(net, PoseResNet) and net.training and net.batch_views_in_training
+    return net.to(memory_format=torch.channels_last if (channels_last and not batched_training) else torch.contiguous_format)
 
 
 class PoseResAttnNet(nn.Module):

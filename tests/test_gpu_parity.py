@@ -1199,3 +1199,43 @@ def test_winograd_split_kernels_confine_nonfinite_inputs(kind):
     assert bool((~torch.isfinite(y))[~torch.isfinite(refnf)].all())          # superset of the direct convolution's pattern
 
 
+@pytest.mark.gpu
+def test_backbone_training_pass_batches_views_like_the_per_view_loop(monkeypatch):
+    """PoseResNet.forward_views in TRAIN mode: one (B*V)-image pass with per-view BatchNorm statistics (ViewBatchNorm2d) ==
+    the reference's loop over cameras (lib/models/multi_person_posenet.py:44-47): heat-maps, running statistics, gradients;
+    a backbone whose weights are channels_last keeps the loop"""
+    import copy
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd import pose_resnet as pr
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)       # the same MIOpen kernels every run
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    dev = torch.device("cuda:0")
+    cfg = load_config(None)
+    torch.manual_seed(3)
+    a = pr.PoseResNet(cfg, 18).to(dev).train()
+    for m in a.modules():                                   # the reference's N(0, 1e-3) init gives ~0 everywhere: use a live net
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            torch.nn.init.kaiming_normal_(m.weight)
+    b = copy.deepcopy(a)
+    b.batch_views_in_training = False
+    V, B = 3, 2
+    views = [torch.randn(B, 3, 64, 96, device=dev) for _ in range(V)]
+    ya, yb = a.forward_views(views), b.forward_views(views)
+    scale = max(float(y.detach().abs().max()) for y in yb)
+    for u, w in zip(ya, yb):
+        assert u.shape == w.shape and float((u - w).abs().max()) <= 2e-4 * scale
+    sum((y * y).mean() for y in ya).backward()
+    sum((y * y).mean() for y in yb).backward()
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        g = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 1e-2 * max(g, 1e-12), n        # train-mode BatchNorm backward: rounding is amplified
+    for (n, u), w in zip(a.named_buffers(), b.buffers()):
+        assert torch.allclose(u.float(), w.float(), rtol=1e-4, atol=1e-5 * max(1.0, float(w.float().abs().max()))), n
+    # channels_last weights: the per-view loop (no copies), same numbers again
+    c = copy.deepcopy(b).to(memory_format=torch.channels_last)
+    c.batch_views_in_training = True
+    for u, w in zip(c.forward_views(views), b.forward_views(views)):
+        assert float((u - w).abs().max()) <= 2e-4 * scale
+    # the model-level switch leaves a training backbone in the plain format
+    assert pr.set_backbone_memory_format(a, True).conv1.weight.is_contiguous()
+    assert not pr.set_backbone_memory_format(a.eval(), True).conv1.weight.is_contiguous()

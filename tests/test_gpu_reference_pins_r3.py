@@ -80,13 +80,18 @@ def _rel(a, b):
 # summation order - on these ill-conditioned gradients that alone moved the error against float64 between 3x and 18x the
 # reference's (round 3).  So the two train-step pins run in a CHILD process whose MIOpen user db is a fresh, empty
 # directory, in immediate mode with deterministic kernels: the library's own heuristic choice for gfx950, the same in every
-# run on every box.  The child prints its measured errors as one JSON line; the bounds below are ~3x what was measured that
-# way (profiles/r04_training_pins_measured.json, three boxes).
+# run on every box (the kernel-binary cache is emptied too: with binaries left by other processes the choice moved).  The
+# child prints its measured errors as one JSON line; the bounds below are ~3x the largest value measured that way
+# (profiles/r04_training_pins_measured.json).
 # ---------------------------------------------------------------------------------------------------------------------
 def _child(args, tmp_path):
-    env = dict(os.environ, PYTHONPATH=ROOT, MIOPEN_USER_DB_PATH=str(tmp_path / "miopen_user_db"))
+    # an empty user db AND an empty kernel-binary cache: with binaries left by earlier processes in ~/.cache/miopen the
+    # immediate-mode choice was seen to change (SSV backbone gradient 1.6e-3 .. 1.2e-2 from the reference's by what ran before)
+    env = dict(os.environ, PYTHONPATH=ROOT, MIOPEN_USER_DB_PATH=str(tmp_path / "miopen_user_db"),
+               MIOPEN_CUSTOM_CACHE_DIR=str(tmp_path / "miopen_cache"))
     env.pop("MIOPEN_FIND_MODE", None)
     os.makedirs(env["MIOPEN_USER_DB_PATH"], exist_ok=True)
+    os.makedirs(env["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in args], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
@@ -103,9 +108,11 @@ def _child(args, tmp_path):
     return rec
 
 
-def _train_step_child(tag, deterministic):
+def _train_step_child(tag, deterministic, batched=True):
     """losses and gradients of one supervised train step against the reference's fp32 and float64 runs -> dict"""
     from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
+    from selfpose3d_amd import pose_resnet
+    pose_resnet.PoseResNet.batch_views_in_training = bool(batched)
     dev = torch.device("cuda:0")
     g = gio.load("train_step")
     torch.backends.cudnn.benchmark = False
@@ -157,17 +164,24 @@ def _train_step_child(tag, deterministic):
 # 0.17 % (pose term) away from its float64 rerun: fp32 backward through train-mode BatchNorm over ~20 conv layers is
 # ill-conditioned); bounds = ~3x the largest value measured with the pinned kernel selection, see above.  A wrong gradient
 # (a missing term, a sign) is off by O(1) = 70x .. 600x.
-GRAD_RATIO_BOUND = {"net_grad_final_2d": 3.0, "net_grad_final_3d": 3.2, "net_grad_final": 3.2, "net_grad_root_front": 2.5,   # measured 0.81 1.06 1.06 0.75
-                    "gt_grad_final_2d": 3.0, "gt_grad_final_cord": 16.0, "gt_grad_final": 16.0, "gt_grad_pose_out": 8.0}     # measured 0.81 5.24 5.24 2.1-2.7
+# Both backbone passes are pinned: "batched" (this repo's default, 6 % faster train step: one pass over all views with
+# per-view BatchNorm statistics, pose_resnet.ViewBatchNorm2d) and "loop" (one call per camera, as the reference) - the same
+# arithmetic, other convolution kernels.  Even with the selection pinned the ill-conditioned terms move from run to run
+# (atomic split-K weight-gradient kernels, fp32 atomics of the scatter): measured over 8 child runs on 3 boxes, batched / loop:
+# 3-D term 0.91-1.06 / 1.06, first root-V2V layer 0.82-1.40 / 0.75, pose term 4.9-8.1 / 5.2, pose head 2.5-3.4 / 2.3-2.7.
+GRAD_RATIO_BOUND = {"net_grad_final_2d": 3.0, "net_grad_final_3d": 3.2, "net_grad_final": 3.2, "net_grad_root_front": 4.2,
+                    "gt_grad_final_2d": 3.0, "gt_grad_final_cord": 24.0, "gt_grad_final": 24.0, "gt_grad_pose_out": 10.0}
 GRAD_FLOOR = 1e-4          # where the problem is well conditioned both errors are ~1e-6: a ratio means nothing below this
 
 
 @pytest.mark.parametrize("deterministic", [False, True])
-@pytest.mark.parametrize("tag", ["net", "gt"])
-def test_supervised_train_step_vs_reference(dev, tag, deterministic, tmp_path):
+@pytest.mark.parametrize("tag,views", [("net", "batched"), ("gt", "batched"), ("net", "loop"), ("gt", "loop")])
+def test_supervised_train_step_vs_reference(dev, tag, views, deterministic, tmp_path):
     """losses <= 1e-4 relative; gradients against the reference's fp32 AND float64 runs, with the scatter and the
-    deterministic unprojection backward"""
-    rec = _child(["--train-step-child", tag, int(deterministic)], tmp_path)
+    deterministic unprojection backward, with the backbone's views batched (default) and looped"""
+    if views == "loop" and deterministic:
+        pytest.skip("the deterministic scatter is pinned with the default backbone pass")
+    rec = _child(["--train-step-child", tag, int(deterministic), int(views == "batched")], tmp_path)
     print(json.dumps(rec))
     assert rec["hm_sum_rel"] <= 1e-4 and rec["valid_equal"]
     for name in ("loss_2d", "loss_3d", "loss_cord"):
@@ -185,8 +199,10 @@ def test_supervised_train_step_vs_reference(dev, tag, deterministic, tmp_path):
         assert rec["pose_out_grad_absmax"] == 0.0           # pose net not reached: zero-anchored, exactly zero gradient
 
 
-def _ssv_step_child():
+def _ssv_step_child(batched=True):
     from selfpose3d_amd.models import get_multi_person_pose_net
+    from selfpose3d_amd import pose_resnet
+    pose_resnet.PoseResNet.batch_views_in_training = bool(batched)
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = False
     torch.backends.cudnn.deterministic = True
@@ -221,12 +237,13 @@ def _ssv_step_child():
 # SSV step: joints in mm on 2000 mm cubes of 62.5 mm voxels (the soft-argmax of a random-weight pose net amplifies the
 # library convolutions' rounding; a wrong cube or joint is off by >= a voxel), gradients relative to the reference's fp32
 # gradient; ~3x the largest value measured with the pinned kernel selection.
-SSV_JOINTS_MM = 3.0                                                                  # measured 0.97
-SSV_GRAD_REL = {"grad_final": 5e-3, "grad_pose_out": 4e-3, "grad_attn_final": 2.5e-4}     # measured 1.6e-3, 1.3e-3, 6.8e-5
+SSV_JOINTS_MM = 4.0                                                                  # measured 0.49-1.55 over 8 runs
+SSV_GRAD_REL = {"grad_final": 1e-2, "grad_pose_out": 8e-3, "grad_attn_final": 2.5e-4}     # measured 1.0e-3-2.3e-3, 4.9e-4-2.6e-3, 2.9e-5-7.4e-5
 
 
-def test_ssv_train_step_vs_reference(dev, tmp_path):
-    rec = _child(["--ssv-step-child"], tmp_path)
+@pytest.mark.parametrize("views", ["batched", "loop"])
+def test_ssv_train_step_vs_reference(dev, views, tmp_path):
+    rec = _child(["--ssv-step-child", int(views == "batched")], tmp_path)
     print(json.dumps(rec))
     assert rec["keys_equal"] and rec["valid_equal"]
     for k, e in rec["loss_rel"].items():
@@ -250,6 +267,6 @@ def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     if sys.argv[1] == "--train-step-child":
-        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])))))
+        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])), bool(int(sys.argv[4])))))
     elif sys.argv[1] == "--ssv-step-child":
-        print(json.dumps(_ssv_step_child()))
+        print(json.dumps(_ssv_step_child(bool(int(sys.argv[2])))))

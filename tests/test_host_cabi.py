@@ -368,3 +368,36 @@ def test_three_piece_weight_splits_are_exact_and_laid_out_as_documented():
     back = ((hi + mid) + lo).permute(0, 1, 2, 4, 3).reshape(27, 16, 32)
     want = w.permute(4, 3, 2, 1, 0).reshape(27, 16, 32)                         # tap = kz*9 + ky*3 + kx
     assert torch.equal(back, want)
+
+
+def test_view_batchnorm_equals_the_per_view_loop():
+    """ViewBatchNorm2d on a sample-major (B*V) batch == BatchNorm2d called once per view (the reference's loop over cameras,
+    lib/models/multi_person_posenet.py:44-47): outputs, input / weight / bias gradients, and the running statistics after
+    the V sequential momentum updates - float64 on the CPU, to rounding"""
+    import copy
+    import torch
+    from selfpose3d_amd.pose_resnet import ViewBatchNorm2d
+    torch.manual_seed(0)
+    V, B, C, H, W = 5, 2, 7, 6, 5
+    bn = ViewBatchNorm2d(C, momentum=0.1).double()
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-1, 1)
+    bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    ref = copy.deepcopy(bn)
+    views = [torch.randn(B, C, H, W, dtype=torch.double, requires_grad=True) for _ in range(V)]
+    wgt = [torch.randn(B, C, H, W, dtype=torch.double) for _ in range(V)]
+    sum((ref(v) * w).sum() for v, w in zip(views, wgt)).backward()
+    views2 = [v.detach().clone().requires_grad_(True) for v in views]
+    bn.views = V
+    y = bn(torch.stack(views2, 1).flatten(0, 1)).view(B, V, C, H, W)
+    sum((y[:, i] * w).sum() for i, w in enumerate(wgt)).backward()
+    outs_ref = [copy.deepcopy(ref).train()(v) for v in views]                    # statistics of each view alone
+    for i in range(V):
+        assert (y[:, i] - outs_ref[i]).abs().max() < 1e-12
+        assert (views2[i].grad - views[i].grad).abs().max() < 1e-10
+    assert (bn.weight.grad - ref.weight.grad).abs().max() < 1e-9 and (bn.bias.grad - ref.bias.grad).abs().max() < 1e-9
+    assert (bn.running_mean - ref.running_mean).abs().max() < 1e-13 and (bn.running_var - ref.running_var).abs().max() < 1e-13
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == V
+    # views = 1 / eval mode: plain BatchNorm2d
+    bn.views = 1
+    x = torch.randn(3, C, H, W, dtype=torch.double)
+    assert torch.equal(bn.eval()(x), ref.eval()(x)) or (bn.eval()(x) - ref.eval()(x)).abs().max() < 1e-12
