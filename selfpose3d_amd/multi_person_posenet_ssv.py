@@ -85,7 +85,7 @@ class MultiPersonPoseNetSSV(nn.Module):
         all_heatmaps = self._heatmaps(views, input_heatmaps)                     # :106-113
         attns = None
         if visualize_attn and views is not None:                                # :115-120
-            attns = torch.stack([self.attn(v) for v in views], 0)
+            attns = torch.stack(self.attn.forward_views(views), 0)
         device = all_heatmaps[0].device
         B = all_heatmaps[0].shape[0]
         if self.use_root_gt:                                                     # :125-132
@@ -170,9 +170,9 @@ class MultiPersonPoseNetSSV(nn.Module):
         attns1 = attns2 = None
         if self.WITH_ATTN:                                                       # :234-244
             if views1 is not None:
-                attns1 = torch.stack([self.attn(v) for v in views1], 0)
+                attns1 = torch.stack(self.attn.forward_views(views1), 0)
             if views2 is not None:
-                attns2 = torch.stack([self.attn(v) for v in views2], 0)
+                attns2 = torch.stack(self.attn.forward_views(views2), 0)
         hm1 = self._heatmaps(views1, input_heatmaps1)
         hm2 = self._heatmaps(views2, input_heatmaps2)
         device = hm1[0].device

@@ -226,6 +226,11 @@ class PoseResAttnNet(nn.Module):
     def forward(self, x):
         return self.sigmoid(self.backbone(x))
 
+    def forward_views(self, views: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """list[V] of (B,3,H,W) -> list[V] of (B,J,h,w): the views in one pass of the backbone (PoseResNet.forward_views:
+        running statistics in eval mode, per-view BatchNorm statistics in train mode) == [self(v) for v in views]"""
+        return [self.sigmoid(y) for y in self.backbone.forward_views(views)]
+
 
 def _load_pretrained(net, cfg, is_train):
     import os
