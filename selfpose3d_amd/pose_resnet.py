@@ -161,8 +161,10 @@ class PoseResNet(nn.Module):
         return (out, feat) if attn else out
 
     def forward_views(self, views: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """list[V] of (B,3,H,W) -> list[V] of (B,J,h,w): one (V*B)-image pass instead of V passes.
-        Identical to the per-view loop whenever BatchNorm is in eval mode (running statistics).
+        """list[V] of (B,3,H,W) -> list[V] of (B,J,h,w): one (V*B)-image pass instead of V passes.  In eval mode BatchNorm uses
+        running statistics and the batch is free to hold all views; in train mode ViewBatchNorm2d keeps the statistics of
+        each view's B images apart, so both are the per-view loop's numbers (the loop itself remains for CPU tensors,
+        channels_last weights, partly frozen BatchNorm or ``batch_views_in_training = False``).
 
         On the GPU the 1x1 head runs with its filter bank zero-padded to ceil4(J) outputs in channels_last, so its
         result IS the (V,B,h,w,Jp) buffer the unprojection kernel gathers from; the returned per-view tensors are
@@ -172,12 +174,14 @@ class PoseResNet(nn.Module):
             # weights in channels_last make every convolution emit channels_last, which the (B, V*C, H, W) view of
             # ViewBatchNorm2d cannot address: such a backbone keeps the per-view loop (MultiPersonPoseNet.use_channels_last
             # leaves a training backbone in the plain format)
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
             if (not self.batch_views_in_training or V == 1 or not views[0].is_cuda or
-                    not self.conv1.weight.is_contiguous()):
+                    not self.conv1.weight.is_contiguous() or
+                    not all(isinstance(m, ViewBatchNorm2d) and m.training and m.track_running_stats and m.momentum is not None
+                            for m in bns)):
                 return [self.forward(v) for v in views]
             # one pass over all views with per-view BatchNorm statistics (ViewBatchNorm2d): the V x fewer, V x larger
             # kernels of the same arithmetic; gradients of the shared weights need no accumulation across calls
-            bns = [m for m in self.modules() if isinstance(m, ViewBatchNorm2d)]
             for m in bns:
                 m.views = V
             try:
