@@ -1202,12 +1202,15 @@ def test_winograd_split_kernels_confine_nonfinite_inputs(kind):
 @pytest.mark.gpu
 def test_backbone_training_pass_batches_views_like_the_per_view_loop(monkeypatch):
     """PoseResNet.forward_views in TRAIN mode: one (B*V)-image pass with per-view BatchNorm statistics (ViewBatchNorm2d) ==
-    the reference's loop over cameras (lib/models/multi_person_posenet.py:44-47): heat-maps, running statistics, gradients;
-    a backbone whose weights are channels_last keeps the loop"""
+    the reference's loop over cameras (lib/models/multi_person_posenet.py:44-47).  In FLOAT64 on the GPU heat-maps, running
+    statistics and every parameter's gradient agree to rounding (fp32 gradients through train-mode BatchNorm are
+    ill-conditioned: the two passes use different convolution kernels and differ by percents there, as the reference's own
+    fp32 run does from its float64 rerun); in fp32 the heat-maps agree to 2e-4; a backbone whose weights
+    are channels_last keeps the loop"""
     import copy
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd import pose_resnet as pr
-    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)       # the same MIOpen kernels every run
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
     monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     dev = torch.device("cuda:0")
     cfg = load_config(None)
@@ -1216,25 +1219,35 @@ def test_backbone_training_pass_batches_views_like_the_per_view_loop(monkeypatch
     for m in a.modules():                                   # the reference's N(0, 1e-3) init gives ~0 everywhere: use a live net
         if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
             torch.nn.init.kaiming_normal_(m.weight)
+    V, B = 3, 2
+    views = [torch.randn(B, 3, 128, 192, device=dev) for _ in range(V)]
+    for dt, out_tol, grad_tol in ((torch.float64, 1e-9, 1e-7), (torch.float32, 2e-4, None)):
+        na = copy.deepcopy(a).to(dt)
+        nb = copy.deepcopy(na)
+        nb.batch_views_in_training = False
+        vv = [v.to(dt) for v in views]
+        ya, yb = na.forward_views(vv), nb.forward_views(vv)
+        scale = max(float(y.detach().abs().max()) for y in yb)
+        for u, w in zip(ya, yb):
+            assert u.shape == w.shape and float((u - w).detach().abs().max()) <= out_tol * scale, dt
+        for (n, u), w in zip(na.named_buffers(), nb.buffers()):
+            assert torch.allclose(u.double(), w.double(), rtol=1e-4 if dt == torch.float32 else 1e-10,
+                                  atol=(1e-5 if dt == torch.float32 else 1e-11) * max(1.0, float(w.double().abs().max()))), (n, dt)
+        if grad_tol is None:
+            continue
+        sum((y * y).mean() for y in ya).backward()
+        sum((y * y).mean() for y in yb).backward()
+        for (n, p), q in zip(na.named_parameters(), nb.parameters()):
+            g = float(q.grad.abs().max())
+            assert float((p.grad - q.grad).abs().max()) <= grad_tol * max(g, 1e-30), (n, dt)
+    # channels_last weights: the per-view loop (no copies), same numbers again
     b = copy.deepcopy(a)
     b.batch_views_in_training = False
-    V, B = 3, 2
-    views = [torch.randn(B, 3, 128, 192, device=dev) for _ in range(V)]      # deep layers: statistics over 2 x 4 x 6 values
-    ya, yb = a.forward_views(views), b.forward_views(views)
-    scale = max(float(y.detach().abs().max()) for y in yb)
-    for u, w in zip(ya, yb):
-        assert u.shape == w.shape and float((u - w).detach().abs().max()) <= 2e-4 * scale
-    sum((y * y).mean() for y in ya).backward()
-    sum((y * y).mean() for y in yb).backward()
-    for (n, p), q in zip(a.named_parameters(), b.parameters()):
-        g = float(q.grad.abs().max())
-        assert float((p.grad - q.grad).abs().max()) <= 3e-2 * max(g, 1e-12), n        # train-mode BatchNorm over a few dozen values per channel: rounding is amplified (1 % seen)
-    for (n, u), w in zip(a.named_buffers(), b.buffers()):
-        assert torch.allclose(u.float(), w.float(), rtol=1e-4, atol=1e-5 * max(1.0, float(w.float().abs().max()))), n
-    # channels_last weights: the per-view loop (no copies), same numbers again
     c = copy.deepcopy(b).to(memory_format=torch.channels_last)
     c.batch_views_in_training = True
-    for u, w in zip(c.forward_views(views), b.forward_views(views)):
+    yb = b.forward_views(views)
+    scale = max(float(y.detach().abs().max()) for y in yb)
+    for u, w in zip(c.forward_views(views), yb):
         assert float((u - w).detach().abs().max()) <= 2e-4 * scale
     # the model-level switch leaves a training backbone in the plain format
     assert pr.set_backbone_memory_format(a, True).conv1.weight.is_contiguous()
