@@ -401,3 +401,29 @@ def test_view_batchnorm_equals_the_per_view_loop():
     bn.views = 1
     x = torch.randn(3, C, H, W, dtype=torch.double)
     assert torch.equal(bn.eval()(x), ref.eval()(x)) or (bn.eval()(x) - ref.eval()(x)).abs().max() < 1e-12
+
+
+def test_forward_views_keeps_the_per_view_loop_where_the_batched_pass_cannot_run():
+    """CPU tensors, a single view, partly frozen BatchNorm or batch_views_in_training = False: PoseResNet.forward_views in
+    train mode is the reference's loop over cameras; set_backbone_memory_format leaves a training backbone in NCHW"""
+    import torch
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd import pose_resnet as pr
+    cfg = load_config(None)
+    torch.manual_seed(0)
+    net = pr.PoseResNet(cfg, 18).train()
+    views = [torch.randn(2, 3, 32, 48) for _ in range(3)]
+    calls = []
+    orig = net.forward
+    net.forward = lambda x, *a, **k: (calls.append(tuple(x.shape)), orig(x, *a, **k))[1]
+    out = net.forward_views(views)
+    assert [tuple(o.shape[:2]) for o in out] == [(2, int(cfg.NETWORK.NUM_JOINTS))] * 3
+    assert calls == [(2, 3, 32, 48)] * 3                                  # CPU: one call per view
+    assert all(m.views == 1 for m in net.modules() if isinstance(m, pr.ViewBatchNorm2d))
+    assert pr.set_backbone_memory_format(net, True).conv1.weight.is_contiguous()            # training + batching: stays NCHW
+    net.batch_views_in_training = False
+    assert not pr.set_backbone_memory_format(net, True).conv1.weight.is_contiguous()        # loop mode: channels_last is fine
+    assert pr.set_backbone_memory_format(net, False).conv1.weight.is_contiguous()
+    # state_dict keys are BatchNorm2d's
+    keys = [k for k in net.state_dict() if k.startswith("bn1.")]
+    assert keys == ["bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked"]
