@@ -16,6 +16,7 @@ __device__ __forceinline__ void lds_dma16(uint32_t voff, uint32_t lds_dst, const
 }
 
 // MODE 0: loads into VGPRs, summed.  MODE 1: LDS-DMA, never read back.  MODE 2: LDS-DMA, then ds_read_b128 of the lane's own 16 bytes.
+// MODE 3: as 0, but a wave-load = 8 voxels x the two x-neighbours of a tap pair (128 contiguous bytes, 64-byte aligned start)
 template <int MODE>
 __global__ __launch_bounds__(64) void k(const float4 *__restrict__ src, float *out, int npix, int iters, int lds_bytes_per_wave)
 {
@@ -32,10 +33,15 @@ __global__ __launch_bounds__(64) void k(const float4 *__restrict__ src, float *o
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             s = hash(s + j);
-            const uint32_t px = hash(s + (lane >> 2)) % (uint32_t)npix;          // 16 pixels per instruction
-            off[j] = px * 64u + (lane & 3) * 16u;
+            if (MODE == 3) {
+                const uint32_t px = hash(s + (lane >> 3)) % (uint32_t)(npix - 1);   // 8 pixel pairs per instruction
+                off[j] = px * 64u + (lane & 7) * 16u;
+            } else {
+                const uint32_t px = hash(s + (lane >> 2)) % (uint32_t)npix;          // 16 pixels per instruction
+                off[j] = px * 64u + (lane & 3) * 16u;
+            }
         }
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
             float4 v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(gbase + off[j]);
@@ -84,6 +90,7 @@ int main()
             run<0>("global_load_dwordx4 -> VGPRs", src, out, npix, waves, 200);
             run<1>("global_load_lds_dwordx4 -> LDS (not read back)", src, out, npix, waves, 200);
             run<2>("global_load_lds_dwordx4 -> LDS, ds_read_b128 of own 16 bytes", src, out, npix, waves, 200);
+            run<3>("global_load_dwordx4 -> VGPRs, 8 voxels x an x-pair (128 B runs)", src, out, npix, waves, 200);
         }
         (void)hipFree(src); (void)hipFree(out);
     }
