@@ -170,11 +170,12 @@ class PoseResNet(nn.Module):
         result IS the (V,B,h,w,Jp) buffer the unprojection kernel gathers from; the returned per-view tensors are
         (B,J,h,w) views of it (``project_layer.nhwc_heatmap_views``) and the re-tiling pass disappears."""
         V, B = len(views), views[0].shape[0]
-        if self.training and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.modules()):
+        norm = nn.modules.batchnorm._BatchNorm          # BatchNorm2d, ViewBatchNorm2d, SyncBatchNorm after a conversion, ...
+        if self.training and any(isinstance(m, norm) and m.training for m in self.modules()):
             # weights in channels_last make every convolution emit channels_last, which the (B, V*C, H, W) view of
             # ViewBatchNorm2d cannot address: such a backbone keeps the per-view loop (MultiPersonPoseNet.use_channels_last
             # leaves a training backbone in the plain format)
-            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            bns = [m for m in self.modules() if isinstance(m, norm)]
             if (not self.batch_views_in_training or V == 1 or not views[0].is_cuda or
                     not self.conv1.weight.is_contiguous() or
                     not all(isinstance(m, ViewBatchNorm2d) and m.training and m.track_running_stats and m.momentum is not None
