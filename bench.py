@@ -553,9 +553,9 @@ def unprojection_backward_leg(dev, iters=30):
         _lib.unproject_fwd([packed[i] for i in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, P, J, h, w, cube, gs, img,
                            False, sample_of=sample_of, pass_mask=mask)
 
-        def run(det=False):
+        def run(det=False, scatter=_lib.SCATTER_AUTO):
             return _lib.unproject_bwd_packed(cam, centers, valid, g, mask, B, V, J, 16, h, w, cube, gs, img, sample_of=sample_of,
-                                             deterministic=det, return_packed=True)
+                                             deterministic=det, return_packed=True, scatter=scatter)
         t = float(np.median([event_time_ms(run, iters, dev) for _ in range(3)]))
         td = float(np.median([event_time_ms(lambda: run(True), iters, dev) for _ in range(3)]))
         alg = 4.0 * (P * J * N + 2 * V * B * J * h * w)           # gradient cubes read + gradient maps read-modify-write
@@ -565,12 +565,8 @@ def unprojection_backward_leg(dev, iters=30):
                          "unproject_bwd2_kernel (one memory atomic per tap and 64-byte pixel)"}
         out[name] = rec
         if fine:
-            prev = _lib.set_bwd_scatter(2)
-            try:
-                d2 = run(True)
-                t2 = float(np.median([event_time_ms(run, iters, dev) for _ in range(3)]))
-            finally:
-                _lib.set_bwd_scatter(prev)
+            d2 = run(True, _lib.SCATTER_PER_TAP)
+            t2 = float(np.median([event_time_ms(lambda: run(False, _lib.SCATTER_PER_TAP), iters, dev) for _ in range(3)]))
             d3, f3 = run(True), run(False)
             scale = float(d3.abs().max())
             rec["per_tap_kernel_us"] = round(t2 * 1e3, 1)

@@ -12,7 +12,11 @@
  * Conventions
  *   - plain pointers and sizes only; every pointer except `hm_views` (a HOST array of V
  *     device pointers) and `grid_size` (host) is a DEVICE pointer valid on `stream`'s device;
- *   - the library allocates nothing, keeps no global state, never synchronises the host;
+ *   - the library allocates nothing and never synchronises the host.  It keeps no state that selects behaviour or
+ *     changes a result: every choice is a per-call argument.  Its only writable statics are three caches, each a pure
+ *     function of (device, shape) - the hipFFT plan cache of the frequency-domain convolution (under a mutex), the
+ *     per-device CU count, and the per-device "dynamic-LDS attribute already raised" flags (tests/test_host_cabi.py
+ *     lists the library's writable symbols and fails on any other);
  *     work is enqueued on `stream` (a hipStream_t, NULL = default stream) and is
  *     HIP-graph capturable;
  *   - every output buffer is fully overwritten (no pre-zeroing needed) unless noted;
@@ -177,33 +181,38 @@ int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_layout, int Jp
                              const int32_t *sample_of, const float *centers, const uint8_t *valid, float *cubes,
                              float *grids, uint16_t *pass_mask, int P, int V, int J, int h, int w, int X, int Y, int Z,
                              const float *grid_size, int W_in, int H_in, void *stream);
+/*
+ * Both scatters come in two kernels that give the same sums (the _det pair the same BITS): per tap (one memory atomic per
+ * 2x2 tap and 64-byte pixel), and block merge (an 8x8x4 block of voxels first adds its taps in an LDS patch, 64-bit fixed
+ * point, and every touched pixel leaves once - 3x faster where voxels lie closer than ~2 pixels, the 64^3 person cubes).
+ * `scatter` picks per CALL (the library keeps no selector state); any other value: SP3D_EINVAL.
+ */
+enum {
+    SP3D_SCATTER_AUTO = 0,    /* by voxel pitch: <= 50 mm on every axis -> merge, else per tap */
+    SP3D_SCATTER_PER_TAP = 2,
+    SP3D_SCATTER_MERGE = 3
+};
 int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
                               const float *grad_cubes, const uint16_t *pass_mask, float *grad_packed, int B, int P,
                               int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
-                              int W_in, int H_in, void *stream);
+                              int W_in, int H_in, int scatter, void *stream);
 
 /*
  * DETERMINISTIC form of sp3d_unproject_bwd_packed (the reference's grid_sampler_2d_backward and the
  * fp32 atomics above both sum in hardware order).  Contributions are accumulated in 64-bit FIXED POINT with integer
  * atomics - integer addition is associative, so the result is bit-identical run to run and independent of scheduling.
  *   grad_fixed  (V,B,h,w,Jp) int64, zero-filled by the caller
- *   scale       DEVICE float: a power of two 2^k; a contribution v is added as round(v * scale).  The caller picks k
- *               from max|grad_cubes| so that |v * scale| <= 2^40 (2^23 contributions per pixel then still fit).
+ *   scale       DEVICE float: a power of two 2^k; a contribution v is added as round(v * scale).
+ *               REQUIRED: |v * scale| < 2^50 for every contribution (the merge kernel rounds with the 1.5*2^52 mantissa
+ *               trick, exact only below that; beyond it the two kernels stop agreeing).  The intended choice is k from
+ *               max|grad_cubes| so that |v * scale| <= 2^40: 2^23 contributions per pixel then still fit in 63 bits.
  * sp3d_fixed_to_float(acc, out, scale, n) converts: out[i] = (float)(acc[i] / scale).
  */
 int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
                                   const float *grad_cubes, const uint16_t *pass_mask, int64_t *grad_fixed,
                                   const float *scale, int B, int P, int V, int J, int Jp, int h, int w, int X, int Y,
-                                  int Z, const float *grid_size, int W_in, int H_in, void *stream);
+                                  int Z, const float *grid_size, int W_in, int H_in, int scatter, void *stream);
 int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream);
-/*
- * Both scatters come in two kernels that give the same sums (the _det pair the same BITS): per tap (one memory atomic per
- * 2x2 tap and 64-byte pixel), and block merge (an 8x8x4 block of voxels first adds its taps in an LDS patch, 64-bit fixed
- * point, and every touched pixel leaves once - 3x faster where voxels lie closer than ~2 pixels, the 64^3 person cubes).
- * The library picks by voxel pitch (<= 50 mm: merge).  which: 0 = automatic, 2 = always per tap, 3 = always merge; any
- * other value changes nothing.  Returns the previous setting.  Process-wide; for tests and measurement.
- */
-int sp3d_set_bwd_scatter(int which);
 
 /*
  * core.proposal.nms + ProposalLayer.get_real_loc (lib/core/proposal.py:28-48,

@@ -20,6 +20,7 @@ LAYOUT_NHWC = 1
 OUT_CHANNELS_LAST = 0x100
 HM_BF16 = 0x200
 OUT_BF16 = 0x400
+SCATTER_AUTO, SCATTER_PER_TAP, SCATTER_MERGE = 0, 2, 3      # include/sp3d.h: per-call scatter choice of unproject_bwd_packed
 MAX_VIEWS = 16
 MAX_TOPK = 32
 ABI_VERSION = 2
@@ -28,7 +29,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_set_bwd_scatter", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
 ]
 
 _lib = None
@@ -73,7 +74,7 @@ def load():
     lib.sp3d_unproject_fwd_train.restype = I
     lib.sp3d_unproject_fwd_train.argtypes = [P, I, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, I, I, V]
     lib.sp3d_unproject_bwd_packed.restype = I
-    lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, V]
+    lib.sp3d_unproject_bwd_packed.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, I, I, V]
     lib.sp3d_upsample2x_scatter.restype = I
     lib.sp3d_upsample2x_scatter.argtypes = [P, P, P, P, C.c_int64, I, I, I, I, V]
     lib.sp3d_render_joints_fwd.restype = I
@@ -471,10 +472,12 @@ def channel_shift_act_(y: torch.Tensor, shift: torch.Tensor, mode: int, residual
 
 def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mask: torch.Tensor, batch: int,
                          num_views: int, J: int, jp: int, h: int, w: int, cube_size, grid_size, img_size,
-                         sample_of: Optional[torch.Tensor] = None, deterministic: bool = False, return_packed: bool = False):
+                         sample_of: Optional[torch.Tensor] = None, deterministic: bool = False, return_packed: bool = False,
+                         scatter: int = SCATTER_AUTO):
     """line-coalesced scatter: -> list[V] of (B,J,h,w) gradient views into one (V,B,h,w,jp) channels-last buffer
     (``return_packed``: that buffer itself, pad channels zero).
-    ``deterministic``: accumulate in 64-bit fixed point (integer atomics): bit-identical run to run."""
+    ``deterministic``: accumulate in 64-bit fixed point (integer atomics): bit-identical run to run.
+    ``scatter``: SCATTER_AUTO (by voxel pitch) / SCATTER_PER_TAP / SCATTER_MERGE - a per-call choice (include/sp3d.h)."""
     lib = load()
     dev = cam.device
     _require_cam(cam)
@@ -484,7 +487,7 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
     if deterministic:
         I, Pp, V_ = C.c_int, C.c_void_p, C.c_void_p
         lib.sp3d_unproject_bwd_packed_det.restype = I
-        lib.sp3d_unproject_bwd_packed_det.argtypes = [Pp] * 8 + [I] * 10 + [Pp, I, I, V_]
+        lib.sp3d_unproject_bwd_packed_det.argtypes = [Pp] * 8 + [I] * 10 + [Pp, I, I, I, V_]
         lib.sp3d_fixed_to_float.restype = I
         lib.sp3d_fixed_to_float.argtypes = [Pp, Pp, Pp, C.c_int64, V_]
         # scale = 2^(40 - ceil(log2 max|g|)): computed on the device, no host synchronisation
@@ -494,7 +497,8 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
         rc = lib.sp3d_unproject_bwd_packed_det(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                                centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),
                                                fixed.data_ptr(), scale.data_ptr(), int(batch), P, num_views, J, jp, h, w,
-                                               X, Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
+                                               X, Y, Z, _f3(grid_size), int(img_size[0]), int(img_size[1]), int(scatter),
+                                               _stream(dev))
         check(rc, "sp3d_unproject_bwd_packed_det")
         packed = torch.empty((num_views, batch, h, w, jp), dtype=torch.float32, device=dev)
         check(lib.sp3d_fixed_to_float(fixed.data_ptr(), packed.data_ptr(), scale.data_ptr(), fixed.numel(), _stream(dev)),
@@ -504,18 +508,9 @@ def unproject_bwd_packed(cam, centers, valid, grad_cubes: torch.Tensor, pass_mas
     rc = lib.sp3d_unproject_bwd_packed(cam.data_ptr(), sample_of.data_ptr() if sample_of is not None else None,
                                        centers.data_ptr(), valid.data_ptr(), gc.data_ptr(), pass_mask.data_ptr(),
                                        packed.data_ptr(), int(batch), P, num_views, J, jp, h, w, X, Y, Z,
-                                       _f3(grid_size), int(img_size[0]), int(img_size[1]), _stream(dev))
+                                       _f3(grid_size), int(img_size[0]), int(img_size[1]), int(scatter), _stream(dev))
     check(rc, "sp3d_unproject_bwd_packed")
     return packed if return_packed else [packed[c].permute(0, 3, 1, 2)[:, :J] for c in range(num_views)]
-
-
-def set_bwd_scatter(which: int) -> int:
-    """which kernel unproject_bwd_packed launches: 0 = by voxel pitch (default), 2 = per-tap scatter, 3 = block merge in LDS.
-    Returns the previous setting (tests and measurement; include/sp3d.h)."""
-    lib = load()
-    lib.sp3d_set_bwd_scatter.restype = C.c_int
-    lib.sp3d_set_bwd_scatter.argtypes = [C.c_int]
-    return int(lib.sp3d_set_bwd_scatter(int(which)))
 
 
 def gaussian_target_3d(roots: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor, gz: torch.Tensor, sigma: float):

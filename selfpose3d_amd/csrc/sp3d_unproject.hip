@@ -1921,24 +1921,18 @@ extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_lay
                        (hipStream_t)stream);
 }
 
-// which scatter kernel sp3d_unproject_bwd_packed[_det] launches: 0 = by voxel pitch, 2 = per-tap (bwd2), 3 = block merge (bwd3)
-static int g_bwd_scatter = 0;
-extern "C" int sp3d_set_bwd_scatter(int which)
-{
-    const int prev = g_bwd_scatter;
-    if (which == 0 || which == 2 || which == 3) g_bwd_scatter = which;
-    return prev;
-}
-
+// scatter: which kernel sp3d_unproject_bwd_packed[_det] launches - SP3D_SCATTER_AUTO (by voxel pitch), _PER_TAP (bwd2),
+// _MERGE (bwd3).  A per-call argument: the library keeps no selector state (include/sp3d.h "no global state").
 static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
                            const float *grad_cubes, const uint16_t *pass_mask, void *grad_acc, const float *scale, int B,
                            int P, int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,
-                           int W_in, int H_in, void *stream)
+                           int W_in, int H_in, int scatter, void *stream)
 {
     Geom g;
     int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
     if (rc) return rc;
     if (B <= 0) return SP3D_EINVAL;
+    if (scatter != SP3D_SCATTER_AUTO && scatter != SP3D_SCATTER_PER_TAP && scatter != SP3D_SCATTER_MERGE) return SP3D_EINVAL;
     if (!cam || !centers || !valid || !grad_cubes || !pass_mask || !grad_acc) return SP3D_ENULL;
     if (Jp < J || (Jp & 3) || Jp > 16 || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
     g.sample_of = sample_of;
@@ -1948,7 +1942,7 @@ static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const flo
     // The pixel pitch depends on the cameras (device data); what the host knows is the voxel pitch in mm: <= 50 mm.
     const bool dense = X >= 2 && Y >= 2 && Z >= 2 && (double)grid_size[0] / (X - 1) <= 50.0 &&
                        (double)grid_size[1] / (Y - 1) <= 50.0 && (double)grid_size[2] / (Z - 1) <= 50.0;
-    if (g_bwd_scatter == 3 || (g_bwd_scatter == 0 && dense)) {
+    if (scatter == SP3D_SCATTER_MERGE || (scatter == SP3D_SCATTER_AUTO && dense)) {
         const int nbx = (X + B3_BX - 1) / B3_BX, nby = (Y + B3_BY - 1) / B3_BY, nbz = (Z + B3_BZ - 1) / B3_BZ;
         const size_t lds3 = (size_t)Jp * B3_PXS * sizeof(unsigned long long) + (4 * SP3D_MAX_VIEWS + 4) * sizeof(int);
         // the 16-byte z runs a block reads of the gradient volume share their 256-byte rows with the blocks above and
@@ -1981,21 +1975,22 @@ static int bwd_packed_impl(const float *cam, const int32_t *sample_of, const flo
 extern "C" int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers,
                                          const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
                                          float *grad_packed, int B, int P, int V, int J, int Jp, int h, int w, int X,
-                                         int Y, int Z, const float *grid_size, int W_in, int H_in, void *stream)
+                                         int Y, int Z, const float *grid_size, int W_in, int H_in, int scatter,
+                                         void *stream)
 {
     return bwd_packed_impl(cam, sample_of, centers, valid, grad_cubes, pass_mask, grad_packed, nullptr, B, P, V, J, Jp, h, w,
-                           X, Y, Z, grid_size, W_in, H_in, stream);
+                           X, Y, Z, grid_size, W_in, H_in, scatter, stream);
 }
 
 extern "C" int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sample_of, const float *centers,
                                              const uint8_t *valid, const float *grad_cubes, const uint16_t *pass_mask,
                                              int64_t *grad_fixed, const float *scale, int B, int P, int V, int J, int Jp,
                                              int h, int w, int X, int Y, int Z, const float *grid_size, int W_in, int H_in,
-                                             void *stream)
+                                             int scatter, void *stream)
 {
     if (!scale) return SP3D_ENULL;
     return bwd_packed_impl(cam, sample_of, centers, valid, grad_cubes, pass_mask, grad_fixed, scale, B, P, V, J, Jp, h, w, X,
-                           Y, Z, grid_size, W_in, H_in, stream);
+                           Y, Z, grid_size, W_in, H_in, scatter, stream);
 }
 
 extern "C" int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream)

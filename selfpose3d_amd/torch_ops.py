@@ -68,7 +68,9 @@ def unproject_bwd(grad_cubes: torch.Tensor, hm: torch.Tensor, cam: torch.Tensor,
     V, B = int(hm.shape[0]), int(hm.shape[1])
     w, h = int(hm_size[0]), int(hm_size[1])
     camf, cen, val = cam.contiguous().float(), centers.contiguous().float(), valid.contiguous().to(torch.uint8)
-    if J <= 16 and w >= 2 and h >= 2:
+    # (an NHWC input padded to more than 16 channels, or not to a multiple of 4, is outside the packed kernels' range:
+    # it takes the planar scatter below, as before round 4)
+    if J <= 16 and w >= 2 and h >= 2 and (layout != _lib.LAYOUT_NHWC or (jp <= 16 and jp % 4 == 0)):
         # the training pair of the C ABI (include/sp3d.h): one forward pass over channels-last maps for the clamp pass mask,
         # then the line-coalesced / block-merge scatter - 10-50x faster than the planar scatter below, same sums
         if layout == _lib.LAYOUT_NHWC:

@@ -10,3 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "miopen_sensitive: outcome depends on which convolution kernels the MIOpen of the box "
+                            "picks (training pins through the library's backward passes); collected LAST")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Deterministic tests first, library-sensitive ones last: the driver runs ``pytest -x``, and nothing bit-stable may sit
+    behind a test whose outcome depends on a third-party kernel choice (round 4: one such failure hid 14 tests)."""
+    last = [it for it in items if it.get_closest_marker("miopen_sensitive")]
+    if last:
+        first = [it for it in items if not it.get_closest_marker("miopen_sensitive")]
+        items[:] = first + last

@@ -181,6 +181,59 @@ def g_train_step():
     np.savez_compressed(os.path.join(HERE, "train_step.npz"), **rec)
 
 
+def _lift(x):
+    """every floating tensor of a (nested) batch structure -> float64"""
+    if torch.is_tensor(x):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: _lift(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_lift(v) for v in x)
+    return x
+
+
+def _ssv_float64_rerun(mps, cfg, gc32):
+    """float64 rerun of the same reference SSV step (lib/models/multi_person_posenet_ssv.py:197-501): the yardstick for how
+    exact ANY fp32 gradient of this step can be, exactly as g_train_step does for the supervised step.  Runs AFTER the fp32
+    pass (which it leaves bit-for-bit unchanged) on a freshly rebuilt batch: the reference's l1_matching_loss normalises
+    meta['joints'] in place (:166-169), so the fp32 pass's batch is spent."""
+    import utils.cameras as ref_cameras
+    import models.project_layer as ref_pl
+    import models.cuboid_proposal_net_soft as ref_soft
+    unfold32, xform32 = ref_cameras.unfold_camera_param, ref_pl.do_transform
+    out = {}
+    try:
+        ref_pl.do_transform = lambda pts, t: xform32(pts, t.to(pts.dtype))
+        ref_cameras.unfold_camera_param = lambda cam, device=None: tuple(t.double() for t in unfold32(cam, device))
+        torch.set_default_dtype(torch.float64)
+        m64 = mps.get_multi_person_pose_net(cfg, is_train=True)
+        gio.he_fill(m64, seed=191)
+        m64.double().train()
+        m64.root_net.eval()
+        b = gio.train_batch(gio.train_cfg(ssv=True), B=2, seed=7, ssv=True)
+        (in1, t1, w1, d1, m1, _, in2, t2, w2, d2, m2, _, in3, t3, w3, d3, m3, _) = _lift(b)
+        _, _, gc64, l64 = m64(views1=in1, meta1=m1, targets_2d1=t1, weights_2d1=w1, targets_3d1=d1[0],
+                              views2=in2, meta2=m2, targets_2d2=t2, weights_2d2=w2, targets_3d2=d2[0],
+                              views3=in3, meta3=m3, targets_2d3=t3, weights_2d3=w3, targets_3d3=d3[0], epoch=1)
+        # the float64 root net must propose the same cubes, or the two runs are not the same function
+        # (same voxel maxima and validity flags; the mm coordinates differ by the fp32 rounding of get_real_loc)
+        g64, g32 = gc64.detach().numpy(), gc32.numpy().astype(np.float64)
+        same = bool(np.array_equal(g64[:, :, 3] >= 0, g32[:, :, 3] >= 0)
+                    and np.abs(g64[:, :, :3] - g32[:, :, :3])[g32[:, :, 3] >= 0].max() < 1e-2)
+        sum(v.mean() for v in l64.values() if v.requires_grad).backward()
+        out = {"grad_final_f64": m64.backbone.final_layer.weight.grad.numpy().copy(),
+               "grad_pose_out_f64": m64.pose_net.v2v_net.output_layer.weight.grad.numpy().copy(),
+               "grad_attn_final_f64": m64.attn.backbone.final_layer.weight.grad.numpy().copy(),
+               "f64_same_proposals": same, "grid_centers_f64": g64}
+        out.update({"loss_f64_" + k: float(v.mean()) for k, v in l64.items()})
+        print("  float64 rerun: same proposals", same, {k: float(v.mean()) for k, v in l64.items()})
+    finally:
+        torch.set_default_dtype(torch.float32)
+        ref_cameras.unfold_camera_param = unfold32
+        ref_pl.do_transform = xform32
+    return out
+
+
 def g_ssv_train_step():
     import models.multi_person_posenet_ssv as mps
     cfg = _ref_cfg(ssv=True, ROOTNET_ROOTHM=True, ROOTNET_TRAIN_SYNTH=True, FREEZE_ROOTNET=True, TRAIN_BACKBONE=True)
@@ -201,6 +254,7 @@ def g_ssv_train_step():
                grad_pose_out=model.pose_net.v2v_net.output_layer.weight.grad.numpy().copy(),
                grad_attn_final=model.attn.backbone.final_layer.weight.grad.numpy().copy(),
                param_seed=191, data_seed=7, epoch=1)
+    rec.update(_ssv_float64_rerun(mps, cfg, gc.detach()))
     np.savez_compressed(os.path.join(HERE, "ssv_train_step.npz"), **rec)
     print("ssv_train_step:", {k: float(v.mean()) for k, v in losses.items()}, "valid", int((gc[:, :, 3] >= 0).sum()))
 

@@ -46,13 +46,9 @@ def _setup(dev, cube, grid_size, hm, J, jp, B=2, V=5, seed=0, centers=None, samp
 
 def _run(which, d, mask, B, V, J, jp, hm, cube, grid_size, deterministic=False):
     from selfpose3d_amd import _lib
-    prev = _lib.set_bwd_scatter(which)
-    try:
-        out = _lib.unproject_bwd_packed(d["cam"], d["cen"], d["val"], d["wgt"], mask, B, V, J, jp, hm[1], hm[0], cube, grid_size,
-                                        IMG, sample_of=d["so"], deterministic=deterministic)
-        return torch.stack([o.contiguous() for o in out])
-    finally:
-        assert _lib.set_bwd_scatter(prev) == which
+    out = _lib.unproject_bwd_packed(d["cam"], d["cen"], d["val"], d["wgt"], mask, B, V, J, jp, hm[1], hm[0], cube, grid_size,
+                                    IMG, sample_of=d["so"], deterministic=deterministic, scatter=which)
+    return torch.stack([o.contiguous() for o in out])
 
 
 CASES = {

@@ -75,27 +75,64 @@ def _rel(a, b):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Training pins.  MIOpen picks a convolution's kernels from its user db when that has an entry for the shape, and another
-# test of the same run (or another process, earlier) may have left one: a different backward algorithm, a different
-# summation order - on these ill-conditioned gradients that alone moved the error against float64 between 3x and 18x the
-# reference's (round 3).  So the two train-step pins run in a CHILD process whose MIOpen user db is a fresh, empty
-# directory, in immediate mode with deterministic kernels: the library's own heuristic choice for gfx950, the same in every
-# run on every box (the kernel-binary cache is emptied too: with binaries left by other processes the choice moved).  The
-# child prints its measured errors as one JSON line; the bounds below are ~3x the largest value measured that way
-# (profiles/r04_training_pins_measured.json).
+# Training pins.  What the library does underneath (round 5, read off MIOPEN_LOG_LEVEL=5 on the GPU box,
+# tools/probe/miopen_log_probe.py): with cudnn.benchmark = False PyTorch still calls miopenFindConvolution*Algorithm, and
+# MIOpen's default find mode DYNAMIC_HYBRID answers a find-db miss by TIMING the applicable kernels ("EvaluateInvokers ...
+# Selected: ...") and keeping the fastest - per process, so the winner of a near-tie depends on the box and on what ran
+# before.  Another backward algorithm = another summation order, and on these ill-conditioned gradients that moved the SSV
+# backbone gradient between 1.0e-3 and 1.22e-2 of the reference's (rounds 3-4; the empty user db / binary cache of round 4
+# did not pin it, they only removed other processes' leftovers).  So the two train-step pins run in a CHILD process
+#   * with MIOPEN_FIND_MODE=FAST: a find-db miss is answered from the library's heuristics, nothing is timed - the same
+#     kernels on every box of one image (SP3D_PINS_FIND_MODE overrides, e.g. DYNAMIC_HYBRID to see the spread);
+#   * with a fresh, empty user db and kernel-binary cache;
+#   * with MIOPEN_LOG_LEVEL=5 into a file, from which the child's record gets a "library" entry: MIOpen version, find mode,
+#     db paths and the solver chosen per direction (FW / BWD / BWrW) with counts - so a surprise explains itself;
+# and the bounds are judged against the reference's float64 reruns, wide enough for ANY kernel choice (see below).
 # ---------------------------------------------------------------------------------------------------------------------
+def _library_record(log_path, env):
+    """what the MIOpen log of the child says: version, find mode, solver per direction"""
+    import collections
+    import re
+    rec = {"find_mode_env": env.get("MIOPEN_FIND_MODE"), "user_db": env.get("MIOPEN_USER_DB_PATH"),
+           "cache_dir": env.get("MIOPEN_CUSTOM_CACHE_DIR"), "solvers": {}}
+    chosen = collections.defaultdict(collections.Counter)
+    try:
+        with open(log_path, errors="replace") as f:
+            for ln in f:
+                m = re.search(r"\b(FW|BWD|BWrW) Chosen Algorithm: (\S+)", ln)
+                if m:
+                    chosen[m.group(1)][m.group(2)] += 1
+                    continue
+                m = re.search(r"MIOPEN_FIND_MODE = (\S+)", ln)
+                if m:
+                    rec["find_mode"] = m.group(1)
+                m = re.search(r"MIOpen version (\S+)", ln)
+                if m:
+                    rec["miopen"] = m.group(1)
+                m = re.search(r"Raw device name: (\S+)", ln)
+                if m:
+                    rec["device"] = m.group(1)
+    except OSError as e:
+        rec["log_error"] = str(e)
+    rec["solvers"] = {d: dict(c.most_common()) for d, c in chosen.items()}
+    return rec
+
+
 def _child(args, tmp_path):
-    # an empty user db AND an empty kernel-binary cache: with binaries left by earlier processes in ~/.cache/miopen the
-    # immediate-mode choice was seen to change (SSV backbone gradient 1.6e-3 .. 1.2e-2 from the reference's by what ran before)
     env = dict(os.environ, PYTHONPATH=ROOT, MIOPEN_USER_DB_PATH=str(tmp_path / "miopen_user_db"),
-               MIOPEN_CUSTOM_CACHE_DIR=str(tmp_path / "miopen_cache"))
-    env.pop("MIOPEN_FIND_MODE", None)
+               MIOPEN_CUSTOM_CACHE_DIR=str(tmp_path / "miopen_cache"), MIOPEN_LOG_LEVEL="5",
+               MIOPEN_FIND_MODE=os.environ.get("SP3D_PINS_FIND_MODE", "FAST"))
     os.makedirs(env["MIOPEN_USER_DB_PATH"], exist_ok=True)
     os.makedirs(env["MIOPEN_CUSTOM_CACHE_DIR"], exist_ok=True)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in args], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    log_path = str(tmp_path / "miopen_log.txt")
+    with open(log_path, "w") as log:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in args], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=log, text=True, timeout=900)
+    if r.returncode != 0:
+        tail = [ln for ln in open(log_path, errors="replace") if not ln.startswith("MIOpen(HIP)")][-60:]
+        raise AssertionError(r.stdout[-3000:] + "".join(tail))
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rec["library"] = _library_record(log_path, env)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, "training_pins_measured.json")
@@ -169,11 +206,18 @@ def _train_step_child(tag, deterministic, batched=True):
 # arithmetic, other convolution kernels.  Even with the selection pinned the ill-conditioned terms move from run to run
 # (atomic split-K weight-gradient kernels, fp32 atomics of the scatter): measured over 8 child runs on 3 boxes, batched / loop:
 # 3-D term 0.91-1.06 / 1.06, first root-V2V layer 0.82-1.40 / 0.75, pose term 4.9-8.1 / 5.2, pose head 2.5-3.4 / 2.3-2.7.
-GRAD_RATIO_BOUND = {"net_grad_final_2d": 3.0, "net_grad_final_3d": 3.2, "net_grad_final": 3.2, "net_grad_root_front": 4.2,
-                    "gt_grad_final_2d": 3.0, "gt_grad_final_cord": 24.0, "gt_grad_final": 24.0, "gt_grad_pose_out": 10.0}
+# Round 5: the bounds follow ONE rule, the SSV pin's: absolute bound = min(CAP, max(k x reference's own fp32 error, FLOOR)),
+# k chosen so the absolute bound is >= 4x the largest value ever measured (the round-4 driver box showed the library's
+# kernel choice moving an ill-conditioned gradient 7.5x between boxes of one pool) and CAP = 0.1 keeps every bound >= 10x
+# below an O(1) error.  Absolute bounds: 3-D term / total 0.080 (seen 0.0154), first root-V2V layer 0.046 (0.0054),
+# pose term / total 0.068 (0.0137), pose head 0.042 (0.0057); the well-conditioned 2-D term sits at the floor (seen 4e-7).
+GRAD_RATIO_BOUND = {"net_grad_final_2d": 3.0, "net_grad_final_3d": 5.5, "net_grad_final": 5.5, "net_grad_root_front": 12.0,
+                    "gt_grad_final_2d": 3.0, "gt_grad_final_cord": 40.0, "gt_grad_final": 40.0, "gt_grad_pose_out": 25.0}
 GRAD_FLOOR = 1e-4          # where the problem is well conditioned both errors are ~1e-6: a ratio means nothing below this
+GRAD_CAP = 0.1
 
 
+@pytest.mark.miopen_sensitive
 @pytest.mark.parametrize("deterministic", [False, True])
 @pytest.mark.parametrize("tag,views", [("net", "batched"), ("gt", "batched"), ("net", "loop"), ("gt", "loop")])
 def test_supervised_train_step_vs_reference(dev, tag, views, deterministic, tmp_path):
@@ -190,9 +234,10 @@ def test_supervised_train_step_vs_reference(dev, tag, views, deterministic, tmp_
         assert rec["net_grad_root_out_rel"] <= 1e-4               # needs only the forward pass to be right
     seen = 0
     for key, v in rec.items():
-        if isinstance(v, dict):
+        if isinstance(v, dict) and "err_vs_f64" in v:
             bound = GRAD_RATIO_BOUND[key]
-            assert v["err_vs_f64"] <= max(bound * v["ref_fp32_err_vs_f64"], GRAD_FLOOR), (key, v, bound)
+            assert v["err_vs_f64"] <= min(GRAD_CAP, max(bound * v["ref_fp32_err_vs_f64"], GRAD_FLOOR)), \
+                (key, v, bound, rec.get("library"))
             seen += 1
     assert seen >= 3
     if "pose_out_grad_absmax" in rec:
@@ -230,17 +275,28 @@ def _ssv_step_child(batched=True):
     for nm, got in (("grad_final", model.backbone.final_layer.weight.grad),
                     ("grad_pose_out", model.pose_net.v2v_net.output_layer.weight.grad),
                     ("grad_attn_final", model.attn.backbone.final_layer.weight.grad)):
-        rec[nm] = _rel(got.cpu().numpy(), g[nm])
+        got, ref32, ref64 = got.cpu().numpy(), g[nm], g[nm + "_f64"]
+        e_ref, e_got = _rel(ref32, ref64), _rel(got, ref64)
+        rec[nm] = {"err_vs_f64": e_got, "ref_fp32_err_vs_f64": e_ref, "ratio": e_got / max(e_ref, 1e-30),
+                   "err_vs_ref_fp32": _rel(got, ref32)}
     return rec
 
 
 # SSV step: joints in mm on 2000 mm cubes of 62.5 mm voxels (the soft-argmax of a random-weight pose net amplifies the
-# library convolutions' rounding; a wrong cube or joint is off by >= a voxel), gradients relative to the reference's fp32
-# gradient; ~3x the largest value measured with the pinned kernel selection.
+# library convolutions' rounding; a wrong cube or joint is off by >= a voxel).
+# Gradients are judged like the supervised step's: error against the reference's FLOAT64 rerun of the same step
+# (tests/golden/make_goldens_r3.py _ssv_float64_rerun) as a multiple of the reference's own fp32 error against it.  On CPU
+# the reference's fp32 gradients are 1.4e-3 (backbone) / 3.0e-4 (pose head) / 7.1e-5 (attention head) from float64; this
+# repo's, through MIOpen's backward kernels, were seen between 1.0e-3 and 1.22e-2 / 4.9e-4 and 2.6e-3 / 2.9e-5 and 7.4e-5
+# from the reference's fp32 values - the largest on a box of the round-4 driver run, by which convolution kernels the
+# library chose there.  k = 40 puts the bounds at 5.7e-2 / 1.2e-2 / 2.9e-3: the worst value ever seen passes with 4.7x to
+# spare, and a wrong gradient (a missing term, a sign: off by O(1)) fails by >= 17x.  The bound is capped at 0.1 so that
+# stays true whatever the yardstick file holds.
 SSV_JOINTS_MM = 4.0                                                                  # measured 0.49-1.55 over 8 runs
-SSV_GRAD_REL = {"grad_final": 1e-2, "grad_pose_out": 8e-3, "grad_attn_final": 2.5e-4}     # measured 1.0e-3-2.3e-3, 4.9e-4-2.6e-3, 2.9e-5-7.4e-5
+SSV_GRAD_K, SSV_GRAD_FLOOR, SSV_GRAD_CAP = 40.0, 1e-4, 0.1
 
 
+@pytest.mark.miopen_sensitive
 @pytest.mark.parametrize("views", ["batched", "loop"])
 def test_ssv_train_step_vs_reference(dev, views, tmp_path):
     rec = _child(["--ssv-step-child", int(views == "batched")], tmp_path)
@@ -249,10 +305,13 @@ def test_ssv_train_step_vs_reference(dev, views, tmp_path):
     for k, e in rec["loss_rel"].items():
         assert e <= 2e-4, (k, e)
     assert rec["joints_mm"] <= SSV_JOINTS_MM, rec
-    for nm, bound in SSV_GRAD_REL.items():
-        assert rec[nm] <= bound, (nm, rec[nm], bound)       # a wrong gradient is off by O(1)
+    for nm in ("grad_final", "grad_pose_out", "grad_attn_final"):
+        v = rec[nm]
+        bound = min(max(SSV_GRAD_K * v["ref_fp32_err_vs_f64"], SSV_GRAD_FLOOR), SSV_GRAD_CAP)
+        assert v["err_vs_f64"] <= bound, (nm, v, bound, rec.get("library"))
 
 
+@pytest.mark.miopen_sensitive
 def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
     """drop-in check: tools/train_3d.py dispatches MODEL multi_person_posenet_ssv / WITH_SSV to the
     self-supervised loop and model, two iterations + validation on synthetic three-set frames"""

@@ -44,6 +44,31 @@ def test_every_declared_symbol_is_exported(lib):
         assert m and int(m.group(1)) == val, macro
 
 
+def test_library_keeps_no_selector_state(lib):
+    """include/sp3d.h: no state that selects behaviour (round 4 had a process-wide scatter selector; round 5: a per-call
+    argument).  Every writable symbol of the library is either the toolchain's / HIP runtime's registration data or one of
+    the three documented caches."""
+    import subprocess
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    runtime = re.compile(r"_kernel(<.*>)?\(|__hip_|__do_|_DYNAMIC|_GLOBAL_OFFSET_TABLE_|__dso_handle|DW\.ref|__fini|__init|"
+                         r"__TMC_END__|completed\.|__bss_start|_edata|_end$")
+    documented = ("g_mu", "g_plans", "attr_set", "attr_dev", "cu_count")
+    writable = [ln.split(None, 2)[2] for ln in out.splitlines() if re.match(r"^[0-9a-f]+ [bBdDsScC] ", ln)]
+    assert len(writable) > 10                                   # (nm really listed the library)
+    own = [w for w in writable if not runtime.search(w)]
+    stray = [w for w in own if not w.endswith(documented)]
+    assert not stray, stray
+    assert not hasattr(lib, "sp3d_set_bwd_scatter")
+    # the per-call selector is validated before any launch
+    gs = (C.c_float * 3)(2000, 2000, 2000)
+    d = C.c_void_p(0x1000)
+    f = lib.sp3d_unproject_bwd_packed
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 7 + [C.c_int] * 10 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    assert f(d, None, d, d, d, d, d, 1, 1, 2, 15, 16, 8, 8, 4, 4, 4, gs, 96, 72, 1, None) == -1        # scatter = 1: EINVAL
+    assert f(d, None, d, d, d, d, None, 1, 1, 2, 15, 16, 8, 8, 4, 4, 4, gs, 96, 72, _lib.SCATTER_MERGE, None) == -2
+
+
 def test_argument_validation_before_any_launch(lib):
     gs = (C.c_float * 3)(8000, 8000, 2000)
     views = (C.c_void_p * 2)(0x1000, 0x1000)      # never dereferenced: validation fails first
