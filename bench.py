@@ -673,6 +673,12 @@ def train_step_leg(args, rank, world, dev):
         state["loss"] = loss
         return loss
     el, _ = D.timed_steps(step, args.train_steps, args.train_warmup, dev)
+    host = None
+    if "host_contention" in args.legs_list and world == 1:
+        try:
+            host = D.host_contention(step, args.train_steps, dev)
+        except Exception as e:
+            host = {"error": f"{type(e).__name__}: {e}"}
     V = len(inputs)
     persons = int(sum(int(n) for n in meta[0]["num_person"]))
     pose_calls = int(max(int(n) for n in meta[0]["num_person"]))         # one pose-net call per candidate slot in use
@@ -684,6 +690,7 @@ def train_step_leg(args, rank, world, dev):
             "collective": ((("DDP gradient all-reduce over gloo, all ranks on cuda:0 (--share-gpu smoke)" if args.share_gpu else
                              "DDP gradient all-reduce over RCCL (backend nccl)") + ", bucket_cap 32 MB, overlapped with backward")
                            if world > 1 else "none (single process)"),
+            "host_contention": host,
             "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
             "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
             "loss_last": float(state["loss"].detach()), "data": "synthetic frames built once per rank, resident on the device",
@@ -755,7 +762,9 @@ def main():
     cfg, meta, hms, model, golden = build_workload(args.batch, rank, dev, args.v2v_layout, args.front_conv,
                                                    not args.no_winograd, args.planar_input, not args.no_gemm_tuning)
     legs = args.legs.split(",") if args.legs not in ("auto", "none") else \
-        ([] if args.legs == "none" else ["pose_stage", "planar_handover", "unprojection_grids", "unprojection_backward", "train_step"])
+        ([] if args.legs == "none" else ["pose_stage", "planar_handover", "unprojection_grids", "unprojection_backward", "train_step",
+                                         "host_contention"])
+    args.legs_list = legs
 
     from selfpose3d_amd.project_layer import clear_pack_cache
 
@@ -792,6 +801,18 @@ def main():
 
     # ---- extra legs that every rank takes part in (same timing rule); rank 0 adds them to the one JSON line -----------
     extra = {}
+    if "host_contention" in legs and world == 1:
+        # host-side readiness for 8 ranks per node, measured on this 1-GPU box: the headline step (one graph replay + the
+        # camera-table pack per step) and, in the train leg, the ~3 500-launch train step, re-timed with this process
+        # confined to 1/8 of the host's cores and with the other 7/8 busy
+        try:
+            extra["host_contention"] = {"headline_step": D.host_contention(step, args.steps, dev),
+                                        "what": "this process pinned to 1/8 of the host cores with one compute thread, then "
+                                                "the same with a spinning process on every other core (7 busy neighbour "
+                                                "ranks); host_ms_per_step = CPU time of the Python thread per step; the train "
+                                                "step under the same conditions: legs.train_step.host_contention"}
+        except Exception as e:
+            extra["host_contention"] = {"error": f"{type(e).__name__}: {e}"}
     if "planar_handover" in legs and not args.planar_input:
         # the reference hands the heat-maps over planar, (B,15,h,w) per view: the same step + the re-tiling pass
         try:
@@ -859,6 +880,9 @@ def main():
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
                        "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
             "views_x_frames_per_s": round(value * V, 3),
+            "value_window": (f"first of {len(spread)} windows of {args.steps} steps; by ms_per_step it ranks "
+                             f"{1 + sorted(spread).index(spread[0])} of {len(spread)} (1 = fastest): legs measured later in the run may read "
+                             f"faster than `value` by up to the box_spread"),
             "box_spread": {"ms_per_step_min": round(min(spread), 4), "ms_per_step_max": round(max(spread), 4),
                            "repeats": len(spread), "steps_each": args.steps,
                            "what": "the timed K steps (= value) and further repeats of K steps on the same box, same rule"},
@@ -898,6 +922,29 @@ def main():
                 model.v2v_net.invalidate_plan()
         result["roofline"] = roofline_leg(cfg, meta, hms, model, args.roofline_iters, dev, args.planar_input,
                                           cold=not args.no_cold)
+        if mode == "hipgraph":
+            # the unprojection's time INSIDE the replayed step, from the step's own graph: a second capture of the same
+            # step with two external timing-event nodes around ProjectLayer.get_voxel (the headline graph carries none)
+            try:
+                from selfpose3d_amd.graphs import GraphedRootNet
+                g_t = GraphedRootNet(model, hms, meta, time_unprojection=True)
+                ts = []
+                for i in range(60):
+                    g_t()
+                    if i >= 10:
+                        ts.append(g_t.unprojection_ms())
+                t_med = float(np.median(ts))
+                alg = float(result["roofline"]["algorithmic_bytes"]) if "algorithmic_bytes" in result["roofline"] else None
+                rec = {"kernel_us": round(t_med * 1e3, 2), "min_us": round(min(ts) * 1e3, 2), "max_us": round(max(ts) * 1e3, 2),
+                       "replays": len(ts),
+                       "source": "external timing-event nodes around ProjectLayer.get_voxel inside the replayed HIP graph of the "
+                                 "step (includes the event nodes' own latency, ~2-5 us)"}
+                if alg:
+                    rec["frac"] = round(alg / (t_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                result["roofline"]["in_step_graph_events"] = rec
+                del g_t
+            except Exception as e:
+                result["roofline"]["in_step_graph_events"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(cfg, meta, hms, model, args.cpu_baseline_reps)
         else:

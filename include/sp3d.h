@@ -389,6 +389,38 @@ int sp3d_upsample2x_scatter(const float *G, float *out, const float *shift, cons
 int sp3d_upsample2x_scatter_head(const float *G, float *head, const float *shift, const float *skip, const float *wout,
                                  const float *bout, int64_t batch, int X, int Y, int Z, int O, int J, void *stream);
 
+/*
+ * GROUPED training-mode batch normalisation on channels-last tensors (round 5): what lets the training pose net run all
+ * candidate slots - and the backbone all cameras - as ONE batch and still be the reference's per-call BatchNorm
+ * (lib/models/v2v_net.py:14,28,31,38,64 under the loop of lib/models/multi_person_posenet.py:84-88 and
+ * multi_person_posenet_ssv.py:354-383; lib/models/pose_resnet.py BatchNorm2d under multi_person_posenet.py:44-47).
+ *   x, y, dy, dx   (N, S, C), C contiguous (torch.channels_last / channels_last_3d); dtype SP3D_GBN_F32 | SP3D_GBN_F64;
+ *                  C % 4 == 0 (F32) / C % 2 == 0 (F64), C <= 2048 (F32) / 1024 (F64)
+ *   group_of       int32 (N): group of sample n, any assignment in [0, G)
+ *   group_samples  int32 (G): number of samples in each group (0 allowed: statistics 0 / 1, never used)
+ * per (group g, channel c), over the group's samples x S:  mean = E[x],  var = E[x^2] - mean^2 (float64 accumulation),
+ *   y = (x - mean) / sqrt(var + eps) * weight + bias  [then max(0, .) if relu]
+ * running_mean / running_var (NULL: none) receive the momentum updates of groups 0 .. G_update-1 IN THAT ORDER with the
+ * unbiased variance - the sequence of updates the reference's loop makes (groups >= G_update, e.g. padding cubes, leave
+ * them alone).  mean, invstd, scale, shift: (G, C) outputs, kept by the caller for the backward.
+ * workspace: sp3d_gbn_workspace_bytes(G, C) bytes, ZERO-FILLED by the caller before EACH of the two calls (the
+ * statistics merge with float64 atomics into SP3D_GBN_REPLICAS copies).
+ * backward: dx = d loss / d x given dy = d loss / d y (with relu: dy counts only where y > 0, recomputed from x - y is not
+ * needed); grad_weight, grad_bias (C) summed over all groups (NULL: skipped); k123: scratch of 3 * G * C elements.
+ */
+#define SP3D_GBN_F32 0
+#define SP3D_GBN_F64 1
+#define SP3D_GBN_REPLICAS 16
+int64_t sp3d_gbn_workspace_bytes(int G, int C);
+int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t *group_of, const int32_t *group_samples, int N,
+                     int64_t S, int C, int G, int G_update, const void *weight, const void *bias, void *running_mean,
+                     void *running_var, double eps, double momentum, int relu, void *mean, void *invstd, void *scale,
+                     void *shift, double *workspace, void *stream);
+int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dtype, const int32_t *group_of,
+                      const int32_t *group_samples, int N, int64_t S, int C, int G, const void *weight, const void *mean,
+                      const void *invstd, const void *scale, const void *shift, int relu, void *grad_weight,
+                      void *grad_bias, void *k123, double *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

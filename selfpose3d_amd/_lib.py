@@ -13,7 +13,9 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsp3d.so")
+_DEFAULT_LIB_PATH = os.path.join(_HERE, "libsp3d.so")
+NOPK_LIB_PATH = os.path.join(_HERE, "libsp3d_nopk.so")       # the flavour without packed-fp32 instructions (shared GPUs)
+LIB_PATH = _DEFAULT_LIB_PATH
 
 LAYOUT_PLANAR = 0
 LAYOUT_NHWC = 1
@@ -29,7 +31,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
 ]
 
 _lib = None
@@ -39,11 +41,21 @@ class Sp3dError(RuntimeError):
     pass
 
 
+def shared_gpu() -> bool:
+    """SP3D_SHARED_GPU=1: this process is not alone on its GPU (another process, or a second stream of its own, may run
+    kernels at the same time).  The library flavour without packed-fp32 instructions is loaded then (libsp3d_nopk.so):
+    v_pk_*_f32 results come out wrong while wino_fused16_kernel's matrix instructions run on the same CU
+    (profiles/r04_gpu_sharing_finding.md; tests/test_gpu_shared_gpu.py holds the two-stream regression)."""
+    return os.environ.get("SP3D_SHARED_GPU", "0").lower() in ("1", "true", "yes", "on")
+
+
 def load():
     """dlopen libsp3d.so (building nothing: run `python -m selfpose3d_amd.build` first)."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if shared_gpu() and LIB_PATH == _DEFAULT_LIB_PATH:
+        LIB_PATH = NOPK_LIB_PATH
     if not os.path.exists(LIB_PATH):
         raise Sp3dError(
             f"{LIB_PATH} not found - the HIP extension is not built. Run `python -m selfpose3d_amd.build` "

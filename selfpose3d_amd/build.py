@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip", "sp3d_fft.hip"]
+SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip", "sp3d_fft.hip", "sp3d_gbn.hip"]
 HEADERS = ["sp3d_device.h", "sp3d_proj_pk.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
 LIB = os.path.join(HERE, "libsp3d.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -73,12 +73,32 @@ def build_variant(out: str, extra_flags=()) -> str:
     return out
 
 
+# The second flavour of the library, for a GPU that is SHARED between streams or processes (SP3D_SHARED_GPU=1, _lib.load):
+# no packed-fp32 instruction anywhere (-DSP3D_NO_PK: the hand-written pairs as two plain VALU instructions;
+# -fno-slp-vectorize: none formed by the compiler).  Same bits; profiles/r04_gpu_sharing_finding.md says why it exists.
+NOPK_LIB = os.path.join(HERE, "libsp3d_nopk.so")
+# (-target-feature -packed-fp32-ops: the backend itself stops selecting v_pk_{fma,mul,add}_f32, also for explicit float2 /
+# float4 vector arithmetic; the host half of the compilation answers "not a recognized feature ... (ignoring)")
+NOPK_FLAGS = ["-DSP3D_NO_PK", "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
+def _stale(lib: str) -> bool:
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    objs = _compile_objects(os.path.join(HERE, "build", "obj"), verbose=verbose)
-    _link(objs, LIB + ".tmp", verbose)
-    os.replace(LIB + ".tmp", LIB)
+    if force or needs_build():
+        objs = _compile_objects(os.path.join(HERE, "build", "obj"), verbose=verbose)
+        _link(objs, LIB + ".tmp", verbose)
+        os.replace(LIB + ".tmp", LIB)
+    if force or _stale(NOPK_LIB):
+        objs = _compile_objects(os.path.join(HERE, "build", "obj_nopk"), NOPK_FLAGS, verbose=verbose)
+        _link(objs, NOPK_LIB + ".tmp", verbose)
+        os.replace(NOPK_LIB + ".tmp", NOPK_LIB)
     return LIB
 
 

@@ -17,9 +17,24 @@
 
 namespace sp3d {
 
+#ifndef SP3D_NO_PK
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// -DSP3D_NO_PK (libsp3d_nopk.so, built with -fno-slp-vectorize): the same operations as one plain VALU instruction per
+// component - no v_pk_*_f32 anywhere in the library.  For a GPU that is SHARED (two streams, two processes): packed-fp32
+// results come out wrong while waves of wino_fused16_kernel execute v_mfma_f32_16x16x32_bf16 on the same CU
+// (profiles/r04_gpu_sharing_finding.md, tests/test_gpu_shared_gpu.py); plain VALU is immune.  Same bits, ~6-9 % slower.
+struct v2f {
+    float x, y;
+};
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
 __device__ __forceinline__ v2f pk2(float a) { return v2f{a, a}; }
 
 // One voxel's sample position in view `cm`: everything of project_layer.py:76-90 up to the un-normalised heat-map

@@ -661,6 +661,9 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int n = 0; n < NBW; ++n) acc[a][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef SP3D_W16_SETPRIO
+    __builtin_amdgcn_s_setprio(SP3D_W16_SETPRIO);       // experiment (round 5): wave priority of the matrix-instruction waves
+#endif
 
     // region of one 16-channel chunk: 400 voxels x 4 float4; every thread of the channel group owns PER of them.  The
     // loads of the group's next chunk are issued before the 16 steps of the current one and parked in registers (a
@@ -805,9 +808,16 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int bc = 0; bc < 4; ++bc) {
+#if defined(SP3D_NO_PK) || defined(SP3D_W16_SCALAR_ACC)
+                    for (int e = 0; e < 4; ++e) {     // one v_fma_f32 per component instead of v_pk_fma_f32 pairs
+                        acc[bc][n][e] = fmaf(M0[n][e], cyz[bc], acc[bc][n][e]);
+                        acc[4 + bc][n][e] = fmaf(M1[n][e], cyz[bc], acc[4 + bc][n][e]);
+                    }
+#else
                     const f32x4 cv = {cyz[bc], cyz[bc], cyz[bc], cyz[bc]};
                     acc[bc][n] = __builtin_elementwise_fma(M0[n], cv, acc[bc][n]);
                     acc[4 + bc][n] = __builtin_elementwise_fma(M1[n], cv, acc[4 + bc][n]);
+#endif
                 }
         }
     }

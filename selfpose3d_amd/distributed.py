@@ -109,6 +109,93 @@ def timed_steps(step, steps: int, warmup: int, device=None):
     return max_over_ranks(time.perf_counter() - t0, device), out
 
 
+def timed_steps_host(step, steps: int, device=None):
+    """timed_steps without warm-up that also returns what the HOST spent: (seconds, CPU seconds of the calling Python
+    thread, CPU seconds of the whole process) over the `steps` steps - how close a rank is to being launch-bound"""
+    import time
+    barrier_sync(device)
+    t0, c0, p0 = time.perf_counter(), time.thread_time(), time.process_time()
+    for _ in range(steps):
+        step()
+    c1 = time.thread_time()
+    barrier_sync(device)
+    return max_over_ranks(time.perf_counter() - t0, device), c1 - c0, time.process_time() - p0
+
+
+class HostShare:
+    """Put THIS process where one of 8 ranks of a node would live: all its threads pinned to 1/8 of the host's cores
+    (the first share), one compute thread (OMP_NUM_THREADS=1) - and, with ``burners``, the other 7/8 of the cores kept
+    busy by spinning processes, as 7 busy neighbour ranks would.  No 8-GPU box needed to see whether the launch path of a
+    step survives its share of the host (the reference's DataParallel runs ONE process for 8 GPUs,
+    /root/reference/tools/train_3d.py:105-140; here it is one process per GPU)."""
+
+    def __init__(self, burners: bool = False, shares: int = 8):
+        self.burners, self.shares, self.procs, self.prev, self.prev_threads = burners, shares, [], {}, None
+
+    @staticmethod
+    def _tids():
+        import os
+        return [int(t) for t in os.listdir("/proc/self/task")]
+
+    def __enter__(self):
+        import os
+        import subprocess
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // self.shares)
+        mine, rest = cores[:per], cores[per:per * self.shares]
+        for tid in self._tids():
+            try:
+                self.prev[tid] = os.sched_getaffinity(tid)
+                os.sched_setaffinity(tid, mine)
+            except OSError:
+                pass
+        self.prev_threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        self.cores_used, self.cores_total = len(mine), len(cores)
+        if self.burners:
+            for c in rest:                                     # one spinning shell per remaining core, pinned to it
+                self.procs.append(subprocess.Popen(["taskset", "-c", str(c), "sh", "-c", "while :; do :; done"],
+                                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        for p in self.procs:                                   # exactly the processes started above
+            p.kill()
+        for p in self.procs:
+            p.wait()
+        for tid, mask in self.prev.items():
+            try:
+                os.sched_setaffinity(tid, mask)
+            except OSError:
+                pass
+        torch.set_num_threads(self.prev_threads)
+        return False
+
+
+def host_contention(step, steps: int, device=None, base_ms=None):
+    """{condition: step time + host CPU time per step} for: the host as it is, this rank's 1/8 share of the cores, the
+    same share with the other 7/8 busy.  `step` must already be warm."""
+    out = {}
+    for name, ctx in (("unconstrained", None), ("one_eighth_of_the_cores_1_thread", HostShare(False)),
+                      ("one_eighth_of_the_cores_others_busy", HostShare(True))):
+        if ctx is None:
+            el, cpu_t, cpu_p = timed_steps_host(step, steps, device)
+            rec = {}
+        else:
+            with ctx:
+                timed_steps_host(step, max(2, steps // 4), device)          # settle on the new cores
+                el, cpu_t, cpu_p = timed_steps_host(step, steps, device)
+                rec = {"cores": ctx.cores_used, "of": ctx.cores_total, "burner_processes": len(ctx.procs)}
+        rec.update({"ms_per_step": round(1e3 * el / steps, 4), "host_ms_per_step": round(1e3 * cpu_t / steps, 4),
+                    "process_cpu_ms_per_step": round(1e3 * cpu_p / steps, 4), "steps": steps})
+        out[name] = rec
+    ref = out["unconstrained"]["ms_per_step"]
+    for name, rec in out.items():
+        rec["vs_unconstrained"] = round(rec["ms_per_step"] / ref, 4)
+    return out
+
+
 def job_throughput(units_per_rank_per_step: int, steps: int, seconds: float, world: int) -> float:
     """whole-job units/s under weak scaling: every rank processes its own `units_per_rank_per_step`"""
     return world * units_per_rank_per_step * steps / seconds

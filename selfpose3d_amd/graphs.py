@@ -19,8 +19,13 @@ class GraphedRootNet:
 
     RING = 4      # slots of the pinned ring: the host may run RING - 1 launches ahead of the GPU
 
-    def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3):
+    def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3,
+                 time_unprojection: bool = False):
+        """``time_unprojection``: measurement builds only - the graph carries two EXTERNAL timing-event record nodes
+        around ``ProjectLayer.get_voxel`` so that ``unprojection_ms()`` reads the kernel's time INSIDE the replayed step
+        (between the camera fetch before it and the convolutions behind it), not that of a stand-alone launch."""
         self.net = net
+        self._t0 = self._t1 = None
         self.static_hms: List[torch.Tensor] = list(heatmaps)       # the caller writes new heat-maps into these
         dev = heatmaps[0].device
         pl = net.project_layer
@@ -44,13 +49,35 @@ class GraphedRootNet:
             torch.cuda.current_stream(dev).wait_stream(stream)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
-                _lib.fetch_ring(self._ring, self.cam_dev, self._counter)
-                self.out = net(self.static_hms, meta, flip_xcoords)
+            if time_unprojection:
+                self._t0 = torch.cuda.Event(enable_timing=True, external=True)
+                self._t1 = torch.cuda.Event(enable_timing=True, external=True)
+                inner = pl.get_voxel
+
+                def timed_get_voxel(*a, **k):
+                    self._t0.record()
+                    r = inner(*a, **k)
+                    self._t1.record()
+                    return r
+                pl.get_voxel = timed_get_voxel          # instance attribute: shadows the method while capturing only
+            try:
+                with torch.cuda.graph(self.graph), torch.no_grad():
+                    _lib.fetch_ring(self._ring, self.cam_dev, self._counter)
+                    self.out = net(self.static_hms, meta, flip_xcoords)
+            finally:
+                if time_unprojection:
+                    del pl.get_voxel
         # the captured kernels read the folded inference plan's tensors by address: keep them alive even if the net
         # drops its plan later (train() / load_state_dict / invalidate_plan)
         self._plan = getattr(getattr(net, "v2v_net", None), "_plan", None)
         self._plan_tensors = dict(self._plan.t) if self._plan is not None else None     # incl. the padded FFT buffers
+
+    def unprojection_ms(self) -> float:
+        """time between the two event nodes of the LAST replay (``time_unprojection=True``); synchronises"""
+        if self._t0 is None:
+            raise RuntimeError("GraphedRootNet was not built with time_unprojection=True")
+        torch.cuda.synchronize(self._dev)
+        return float(self._t0.elapsed_time(self._t1))
 
     def _stage(self, meta):
         """camera table of the NEXT fetch launch -> its ring slot (waits only if the GPU is RING launches behind)"""

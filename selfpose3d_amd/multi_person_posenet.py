@@ -9,6 +9,8 @@ MAX_PEOPLE_NUM-iteration loop.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -19,6 +21,8 @@ from .pose_regression_net import PoseRegressionNet
 
 
 class MultiPersonPoseNet(nn.Module):
+    batch_slots_in_training = os.environ.get("SP3D_BATCH_SLOTS", "1") != "0"      # train mode: the pose net sees all candidate slots in one pass (False: one call per slot)
+
     def __init__(self, backbone, cfg):
         super().__init__()
         self.num_cand = int(cfg.MULTI_PERSON.MAX_PEOPLE_NUM)
@@ -90,11 +94,16 @@ class MultiPersonPoseNet(nn.Module):
         have_gt = "joints_3d" in meta[0] and "joints_3d_vis" in meta[0]
         flags = grid_centers[:, :, 3].detach().cpu()                              # one sync for the whole loop
         count = 0
+        # round 5: all slots in ONE pose-net pass whose BatchNorm layers keep every slot's statistics apart
+        # (pose_regression_net.forward_slots) - the loop's results, 3 calls of (2,2,1) cubes -> 1 call of 5
+        slots = None
+        if self.batch_slots_in_training and all_heatmaps[0].is_cuda and self.pose_net.can_batch_slots():
+            slots = self.pose_net.forward_slots([(all_heatmaps, meta, None)], grid_centers, flags=flags)[0]
         for n in range(self.num_cand):
             rows = flags[:, n] >= 0
             if not bool(rows.any()):
                 continue
-            single = self.pose_net(all_heatmaps, meta, grid_centers[:, n])
+            single = slots[:, n] if slots is not None else self.pose_net(all_heatmaps, meta, grid_centers[:, n])
             pred[:, n, :, 0:3] = single.detach()
             if have_gt:                                                          # :92-100 running mean of L1 terms
                 gt_3d = meta[0]["joints_3d"].float().to(device)

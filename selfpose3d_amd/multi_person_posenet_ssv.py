@@ -21,6 +21,8 @@ code of the SSL pipeline are out of scope; ``synthetic_dataset.Syn
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -30,6 +32,8 @@ from .pose_regression_net import PoseRegressionNet
 
 
 class MultiPersonPoseNetSSV(nn.Module):
+    batch_slots_in_training = os.environ.get("SP3D_BATCH_SLOTS", "1") != "0"      # train mode: the pose net sees all slots (and both view sets) in one pass (False: loop)
+
     def __init__(self, backbone, cfg, attn=None):
         super().__init__()
         self.num_cand = int(cfg.MULTI_PERSON.MAX_PEOPLE_NUM)
@@ -142,9 +146,15 @@ class MultiPersonPoseNetSSV(nn.Module):
             return (losses * mask).sum() / (B * V - 1)
         return losses.mean()
 
-    def _pose_pass(self, heatmaps, meta, grid_centers, flip):
-        """pose net on every candidate that has a valid proposal in some sample (:361-381): (B, num_cand, J, 5)"""
+    def _pose_pass(self, heatmaps, meta, grid_centers, flip, poses=None):
+        """pose net on every candidate that has a valid proposal in some sample (:361-381): (B, num_cand, J, 5);
+        ``poses``: (B, num_cand, J, 3) already computed by the slot-batched pass"""
         B = grid_centers.shape[0]
+        tail = grid_centers[:, :, 3:].reshape(B, -1, 1, 2).expand(-1, -1, self.num_joints, -1)
+        if poses is not None:
+            return torch.cat([poses, tail], dim=3)
+        if self.batch_slots_in_training and heatmaps[0].is_cuda and self.pose_net.can_batch_slots():
+            return torch.cat([self.pose_net.forward_slots([(heatmaps, meta, flip)], grid_centers)[0], tail], dim=3)
         pred = torch.zeros(B, self.num_cand, self.num_joints, 5, device=grid_centers.device)
         pred[:, :, :, 3:] = grid_centers[:, :, 3:].reshape(B, -1, 1, 2)
         flags = grid_centers[:, :, 3].detach().cpu()
@@ -251,7 +261,14 @@ class MultiPersonPoseNetSSV(nn.Module):
 
         from .camera_pack import pack_cameras
         count = (grid_centers[:, :, 3] >= 0).sum(1)                              # valid proposals lead the list (:386)
-        pred1 = self._pose_pass(hm1, meta1, grid_centers, flip1)
+        both = None
+        if (self.batch_slots_in_training and not self.single_aug_training_posenet and hm1[0].is_cuda and
+                self.pose_net.can_batch_slots()):
+            # both view sets and all slots in ONE pose-net pass; the grouped BatchNorm layers keep the statistics of each of
+            # the reference's calls apart and update the running statistics in ITS order: slot 0 set 1, slot 0 set 2, slot 1
+            # set 1, ... (multi_person_posenet_ssv.py:361-381)
+            both = self.pose_net.forward_slots([(hm1, meta1, flip1), (hm2, meta2, flip2)], grid_centers)
+        pred1 = self._pose_pass(hm1, meta1, grid_centers, flip1, both[0] if both is not None else None)
         cam = torch.from_numpy(pack_cameras(meta1, B, [self.width, self.height])).to(device)   # proj_cameras (:397)
         trans1 = meta1[0]["trans"]
         have_people = int(count[0]) > 0              # the reference tests sample 0 only (pred1[0].shape[0] > 0, :409,433)
@@ -267,7 +284,7 @@ class MultiPersonPoseNetSSV(nn.Module):
                 reached.add("pose_net")
             return done(pred_out, hm3, grid_centers, losses)
 
-        pred2 = self._pose_pass(hm2, meta2, grid_centers, flip2)
+        pred2 = self._pose_pass(hm2, meta2, grid_centers, flip2, both[1] if both is not None else None)
         pred_out = pred2.detach().clone()
         trans2 = meta2[0]["trans"]
         if have_people:                                                          # :433-486

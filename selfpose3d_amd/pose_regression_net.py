@@ -99,6 +99,78 @@ class PoseRegressionNet(nn.Module):
         pred[bi, ki] = torch.cat(outs, 0)
         return pred
 
+    # cube counts the slot-batched training call may be padded to (zero cubes in a BatchNorm group of their own, dropped
+    # afterwards): None = never pad, every distinct count is its own set of MIOpen convolution shapes (one kernel search
+    # each, kept in the user find-db); a tuple = round up to the next listed size, so the library only ever sees those
+    slot_pad_sizes = None
+
+    def can_batch_slots(self) -> bool:
+        """all normalisation layers still are grouped BatchNorm (a SyncBatchNorm conversion, say, replaces them: then the
+        per-slot loop is the only way to keep the reference's per-call statistics)"""
+        from .grouped_bn import GroupedBatchNorm3d
+        norms = [m for m in self.v2v_net.modules() if isinstance(m, nn.modules.batchnorm._NormBase)]
+        return len(norms) > 0 and all(isinstance(m, GroupedBatchNorm3d) for m in norms)
+
+    def forward_slots(self, sets, grid_centers, flags=None):
+        """TRAIN-mode pose net on every candidate slot of a batch in ONE pass, with autograd - the reference's loop
+        (lib/models/multi_person_posenet.py:84-88; multi_person_posenet_ssv.py:361-381 with two heat-map sets per slot):
+
+            for n in range(num_cand):  if any(flag[:, n] >= 0):  for (heatmaps, meta, flip) in sets:
+                pred[:, n] = pose_net(heatmaps, meta, grid_centers[:, n], flip)      # V2VNet on the VALID cubes of slot n
+
+        Every such call is one BatchNorm batch of its own in the reference; here the cubes of all calls go through V2VNet
+        together and its grouped BatchNorm layers (grouped_bn.py) keep each call's statistics apart and update the running
+        statistics call by call in the loop's order.  ``sets``: list of (all_heatmaps, meta, flip_xcoords);
+        grid_centers (B,K,5); ``flags``: its column 3 on the host (saves the sync).  -> list of (B,K,J,3), one per set."""
+        from .grouped_bn import GroupSpec, bn_groups
+        B, K = grid_centers.shape[:2]
+        device = grid_centers.device
+        J = sets[0][0][0].shape[1]
+        if flags is None:
+            flags = grid_centers[:, :, 3].detach().cpu()
+        pairs = [(b, n) for n in range(K) for b in range(B) if float(flags[b, n]) >= 0]       # slot-major
+        P, ns = len(pairs), len(sets)
+        preds = [torch.zeros(B, K, J, 3, device=device, dtype=sets[0][0][0].dtype) for _ in sets]
+        if P == 0:
+            return preds
+        bi = torch.tensor([b for b, _ in pairs], device=device)
+        ki = torch.tensor([n for _, n in pairs], device=device)
+        centers = grid_centers[bi, ki].detach()                    # (P,5), flags all >= 0 (proposals carry no gradient)
+        slots = sorted({n for _, n in pairs})
+        rank = {n: r for r, n in enumerate(slots)}
+        # group of a cube = its call in the loop's order: (slot rank, set index)
+        group_of, sizes = [], [0] * (len(slots) * ns)
+        for si in range(ns):
+            for _, n in pairs:
+                g = rank[n] * ns + si
+                group_of.append(g)
+                sizes[g] += 1
+        planar = self.v2v_net.wants_planar_input() and sets[0][0][0].is_cuda
+        cl = self.channels_last and not planar
+        cubes, grids = [], []
+        for heatmaps, meta, flip in sets:
+            c, g = self.project_layer.get_voxel(heatmaps, meta, self.grid_size, centers, self.cube_size, flip_xcoords=flip,
+                                                pad_channels=not planar, channels_last=cl, sample_of=bi)
+            cubes.append(c)
+            grids.append(g)
+        x = cubes[0] if ns == 1 else torch.cat(cubes, 0)
+        total, n_update = ns * P, len(sizes)
+        if self.slot_pad_sizes:
+            target = next((s for s in sorted(self.slot_pad_sizes) if s >= total), total)
+            if target > total:                                     # zero cubes, a group of their own, no running update
+                x = torch.cat([x, x.new_zeros((target - total,) + tuple(x.shape[1:]))], 0)
+                group_of += [len(sizes)] * (target - total)
+                sizes = sizes + [target - total]
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last_3d)
+        spec = GroupSpec(sizes, device, group_of=group_of, n_update=n_update)
+        with bn_groups(self.v2v_net, spec):
+            y = self.v2v_net(x)
+        for si in range(ns):
+            poses = self.soft_argmax_layer(y[si * P:(si + 1) * P], grids[si])            # (P,J,3)
+            preds[si] = preds[si].index_put((bi, ki), poses)
+        return preds
+
     def forward(self, all_heatmaps, meta, grid_centers, flip_xcoords=None):
         B, J = all_heatmaps[0].shape[:2]
         device = all_heatmaps[0].device

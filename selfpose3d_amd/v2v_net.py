@@ -16,7 +16,14 @@ import torch.nn.functional as F
 
 
 def _bn(c):
-    return nn.BatchNorm3d(c)
+    # nn.BatchNorm3d (same parameters / buffers / state_dict keys) that can keep the statistics of GROUPS of samples apart
+    # while a GroupSpec is attached in train mode: all candidate slots of the training pose net in one call (grouped_bn.py)
+    from .grouped_bn import GroupedBatchNorm3d
+    return GroupedBatchNorm3d(c)
+
+
+def _grouped(bn, training: bool) -> bool:
+    return training and getattr(bn, "groups", None) is not None
 
 
 def fft_len(n: int) -> int:
@@ -128,6 +135,8 @@ class ConvBnRelu3d(nn.Module):
         self.block = nn.Sequential(PadCinConv3d(cin, cout, k, stride=1, padding=(k - 1) // 2), _bn(cout), nn.ReLU(True))
 
     def forward(self, x):
+        if _grouped(self.block[1], self.training):          # BatchNorm + ReLU in one pass (the ReLU mask is recomputed
+            return self.block[1].grouped_forward(self.block[0](x), relu=True)    # from the input in the backward)
         return self.block(x)
 
 
@@ -141,6 +150,10 @@ class Residual3d(nn.Module):
         self.skip_con = nn.Sequential() if cin == cout else nn.Sequential(nn.Conv3d(cin, cout, 1, 1, 0), _bn(cout))
 
     def forward(self, x):
+        rb = self.res_branch
+        if _grouped(rb[1], self.training):
+            y = rb[4](rb[3](rb[1].grouped_forward(rb[0](x), relu=True)))
+            return F.relu(y + self.skip_con(x), True)
         return F.relu(self.res_branch(x) + self.skip_con(x), True)
 
 
@@ -153,6 +166,8 @@ class Up2x3d(nn.Module):
                                    nn.ReLU(True))
 
     def forward(self, x):
+        if _grouped(self.block[1], self.training):
+            return self.block[1].grouped_forward(self.block[0](x), relu=True)
         return self.block(x)
 
 

@@ -93,3 +93,23 @@ def test_gpus_flag_never_runs_fewer_ranks_silently(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=1" in str(e.value)
+
+
+def test_host_share_pins_restores_and_cleans_up():
+    """legs.host_contention (bench.py): the process is confined to 1/8 of the cores and released again; the burner
+    processes it started are gone afterwards; the record carries step time and host CPU time per condition"""
+    import os
+    from selfpose3d_amd import distributed as D
+    before = os.sched_getaffinity(0)
+    with D.HostShare(burners=True) as h:
+        inside = os.sched_getaffinity(0)
+        pids = [p.pid for p in h.procs]
+        assert len(inside) == max(1, len(before) // 8) and inside <= before
+        assert len(pids) == (len(before) // 8) * 7 if len(before) >= 8 else True
+    assert os.sched_getaffinity(0) == before
+    assert not any(os.path.exists(f"/proc/{p}") for p in pids)
+    rec = D.host_contention(lambda: sum(range(2000)), 5)
+    assert set(rec) == {"unconstrained", "one_eighth_of_the_cores_1_thread", "one_eighth_of_the_cores_others_busy"}
+    for r in rec.values():
+        assert r["ms_per_step"] > 0 and r["host_ms_per_step"] > 0 and "vs_unconstrained" in r
+    assert os.sched_getaffinity(0) == before
