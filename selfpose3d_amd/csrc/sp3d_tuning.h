@@ -8,7 +8,8 @@ extern "C" {
 #endif
 /* variant: bits[1:0] voxels in flight (first NHWC kernel); bit 2: no XCD-affine tile map; bit 3: pipelined
  * per-wave kernel; bit 4: one wave per workgroup; bit 5: 4x4x4 voxel bricks per wave (workgroup = z-stack of bricks);
- * bit 6: with bit 5, every brick its own workgroup; bits 17-20: log2(tiles per XCD chunk)+1; bit 21: plain chunk
+ * bit 6: with bit 5, every brick its own workgroup; bit 10: with bit 5, a workgroup barrier per view (view-synchronous
+ * workgroups); bits 11-13: n * 20 KB of unused LDS per brick workgroup (caps the workgroups resident on a CU); bits 17-20: log2(tiles per XCD chunk)+1; bit 21: plain chunk
  * sweep; bit 24: channels-last output.  Library default: 120 (channels-last result), 56 (planar, Z % 32 == 0), else 24. */
 int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float *cam, const float *centers,
                                const uint8_t *valid, float *cubes, float *grids, int B, int V, int J, int h, int w,
@@ -17,6 +18,8 @@ int sp3d_unproject_fwd_variant(const float *const *hm_views, int Jp, const float
 /* per-wave s_memtime timeline of the pipelined kernel (18 uint64 per wave: start, after P1(0), after each
  * view, ..., [17] = number of cameras seeing the lane-0 voxel); NULL switches it off (tools/wave_timeline.py) */
 int sp3d_debug_set_timeline(void *dev_buffer);
+/* one-thread kernel: *slot = the chip-wide 100 MHz clock.  Two around a kernel inside a captured graph time it in the step. */
+int sp3d_debug_stamp(uint64_t *slot, void *stream);
 #ifdef __cplusplus
 }
 #endif

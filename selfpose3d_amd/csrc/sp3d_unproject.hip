@@ -378,8 +378,10 @@ __device__ __forceinline__ Rec make_record(bool use, float ix, float iy, int w, 
 template <int JP, typename TI, int U = 4>
 __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restrict__ cam, const Geom &g, int bs, float x,
                                            float y, float z, bool inb, float *ws, int lane, float (&acc)[4][4],
-                                           uint32_t &mymask, unsigned long long *tl)
+                                           uint32_t &mymask, unsigned long long *tl, bool vsync = false)
 {
+    // vsync (tuning bit 10, brick kernel only; round-5 L1-residency experiment): a workgroup barrier per view, so that all
+    // waves of a workgroup gather from the SAME view at any time (every wave of the workgroup runs all V iterations)
     constexpr int NQ = JP / 4;
     int *wsi = reinterpret_cast<int *>(ws);
     float4 *ws4 = reinterpret_cast<float4 *>(ws);
@@ -427,6 +429,7 @@ __device__ __forceinline__ void pipe_views(const Views &hm, const float *__restr
 #pragma unroll 1
     for (int c = 0; c < g.V; ++c) {
         SP3D_STAMP(2 + 4 * (c < 7 ? c : 6));
+        if (vsync) __builtin_amdgcn_s_barrier();
         const bool cur = have;
         // wave-uniform row bases (SGPR pairs) + one 32-bit element offset per lane: the four taps of a slot are
         // {vb, vb2} + off (+ JP as an immediate), no 64-bit VALU address arithmetic
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
 #else
         unsigned long long *tl = nullptr;
 #endif
-        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl);
+        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl, (g.xcd_order & 4) != 0);
 
         // view fusion (project_layer.py:96-99) on the gather mapping
         __builtin_amdgcn_wave_barrier();
@@ -1558,7 +1561,21 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         set_xcd_fields(gb, wgs);
         set_brick_fields(gb, nbx * nby, nby);
         constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
-        const size_t blds = (size_t)zw * WLDS * sizeof(float);
+        size_t blds = (size_t)zw * WLDS * sizeof(float);
+        // round-5 L1-residency experiment (measurement only): tuning bit 10 = view-synchronous workgroups (only when every
+        // wave of every workgroup lies inside the volume, so that all of them reach the per-view barrier), bits 11-13 = n:
+        // n * 20 KB of unused LDS per workgroup, which caps the workgroups resident on a CU
+        if (((variant >> 10) & 1) && nwz % zw == 0 && nzc * zw == nwz) gb.xcd_order |= 4;
+        const int ballast = (variant >> 11) & 7;
+        if (ballast) {
+            blds += (size_t)ballast * 20480;
+            if (blds > 65536) {
+                const void *fn = out_cl ? reinterpret_cast<const void *>(unproject_brick_kernel<JP, true, float, float>)
+                                        : reinterpret_cast<const void *>(unproject_brick_kernel<JP, false, float, float>);
+                const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+                if (ea != hipSuccess) return (int)ea;
+            }
+        }
         dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
 #define SP3D_BRICK(CL_, TI_, TO_) \
     hipLaunchKernelGGL((unproject_brick_kernel<JP, CL_, TI_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
@@ -2000,6 +2017,19 @@ extern "C" int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *
     if ((n + 255) / 256 > 0x7fffffff) return SP3D_ERANGE;
     hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long *>(acc), out, scale, (size_t)n);
+    return launch_status();
+}
+
+// measurement only: one thread writes the chip-wide 100 MHz clock (s_memrealtime) to *slot.  Two of them around a kernel
+// inside a captured HIP graph give the kernel's time in the replayed step (bench.py roofline.in_step_graph_stamps; PyTorch's
+// ROCm build refuses timing events inside a capture).
+namespace sp3d {
+__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+} // namespace sp3d
+extern "C" int sp3d_debug_stamp(uint64_t *slot, void *stream)
+{
+    if (!slot) return SP3D_ENULL;
+    hipLaunchKernelGGL(sp3d::stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long *>(slot));
     return launch_status();
 }
 

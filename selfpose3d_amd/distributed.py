@@ -124,13 +124,18 @@ def timed_steps_host(step, steps: int, device=None):
 
 class HostShare:
     """Put THIS process where one of 8 ranks of a node would live: all its threads pinned to 1/8 of the host's cores
-    (the first share), one compute thread (OMP_NUM_THREADS=1) - and, with ``burners``, the other 7/8 of the cores kept
-    busy by spinning processes, as 7 busy neighbour ranks would.  No 8-GPU box needed to see whether the launch path of a
-    step survives its share of the host (the reference's DataParallel runs ONE process for 8 GPUs,
-    /root/reference/tools/train_3d.py:105-140; here it is one process per GPU)."""
+    (the first share), one compute thread (OMP_NUM_THREADS=1) - and, with ``burners``, 7 neighbour "ranks" beside it: on each
+    of the other 7 shares ``busy_per_rank`` spinning processes (a rank of this framework keeps ~2 host threads busy: the
+    Python thread and the HIP runtime's; measured process CPU time / step time = 1.6-2.0).  No 8-GPU box needed to see
+    whether the launch path of a step survives its share of the host (the reference's DataParallel runs ONE process for 8
+    GPUs, /root/reference/tools/train_3d.py:105-140; here it is one process per GPU).
+    (Round 5, first form: a spinner on EVERY other logical CPU, 224 of them - the step took 11x longer although none shared
+    a core with this process: the box's container has a CPU quota, which the spinners exhaust for everybody.  Recorded in
+    DESIGN.md; eight real ranks need ~16 cores, not 256.)"""
 
-    def __init__(self, burners: bool = False, shares: int = 8):
-        self.burners, self.shares, self.procs, self.prev, self.prev_threads = burners, shares, [], {}, None
+    def __init__(self, burners: bool = False, shares: int = 8, busy_per_rank: int = 2):
+        self.burners, self.shares, self.busy_per_rank = burners, shares, busy_per_rank
+        self.procs, self.prev, self.prev_threads = [], {}, None
 
     @staticmethod
     def _tids():
@@ -142,7 +147,7 @@ class HostShare:
         import subprocess
         cores = sorted(os.sched_getaffinity(0))
         per = max(1, len(cores) // self.shares)
-        mine, rest = cores[:per], cores[per:per * self.shares]
+        mine = cores[:per]
         for tid in self._tids():
             try:
                 self.prev[tid] = os.sched_getaffinity(tid)
@@ -153,9 +158,12 @@ class HostShare:
         torch.set_num_threads(1)
         self.cores_used, self.cores_total = len(mine), len(cores)
         if self.burners:
-            for c in rest:                                     # one spinning shell per remaining core, pinned to it
-                self.procs.append(subprocess.Popen(["taskset", "-c", str(c), "sh", "-c", "while :; do :; done"],
-                                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+            for r in range(1, self.shares):                    # neighbour rank r: its own share of the cores
+                share = cores[r * per:(r + 1) * per] or cores[-1:]
+                for k in range(self.busy_per_rank):
+                    c = share[k % len(share)]
+                    self.procs.append(subprocess.Popen(["taskset", "-c", str(c), "sh", "-c", "while :; do :; done"],
+                                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
         return self
 
     def __exit__(self, *exc):
@@ -173,12 +181,27 @@ class HostShare:
         return False
 
 
+def _cpu_quota():
+    """the container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota), or None"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:
+        return None
+
+
 def host_contention(step, steps: int, device=None, base_ms=None):
     """{condition: step time + host CPU time per step} for: the host as it is, this rank's 1/8 share of the cores, the
-    same share with the other 7/8 busy.  `step` must already be warm."""
+    same share with 7 neighbour ranks' worth of busy host threads on the other shares.  `step` must already be warm."""
     out = {}
     for name, ctx in (("unconstrained", None), ("one_eighth_of_the_cores_1_thread", HostShare(False)),
-                      ("one_eighth_of_the_cores_others_busy", HostShare(True))):
+                      ("one_eighth_of_the_cores_7_busy_neighbour_ranks", HostShare(True))):
         if ctx is None:
             el, cpu_t, cpu_p = timed_steps_host(step, steps, device)
             rec = {}
@@ -193,6 +216,7 @@ def host_contention(step, steps: int, device=None, base_ms=None):
     ref = out["unconstrained"]["ms_per_step"]
     for name, rec in out.items():
         rec["vs_unconstrained"] = round(rec["ms_per_step"] / ref, 4)
+    out["container_cpu_quota_cores"] = _cpu_quota()
     return out
 
 

@@ -21,11 +21,11 @@ class GraphedRootNet:
 
     def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3,
                  time_unprojection: bool = False):
-        """``time_unprojection``: measurement builds only - the graph carries two EXTERNAL timing-event record nodes
-        around ``ProjectLayer.get_voxel`` so that ``unprojection_ms()`` reads the kernel's time INSIDE the replayed step
-        (between the camera fetch before it and the convolutions behind it), not that of a stand-alone launch."""
+        """``time_unprojection``: measurement only - the graph carries one-thread clock-stamp kernels around
+        ``ProjectLayer.get_voxel`` so that ``unprojection_us()`` reads the kernel's time INSIDE the replayed step (between
+        the camera fetch before it and the convolutions behind it), not that of a stand-alone launch."""
         self.net = net
-        self._t0 = self._t1 = None
+        self._stamps = None
         self.static_hms: List[torch.Tensor] = list(heatmaps)       # the caller writes new heat-maps into these
         dev = heatmaps[0].device
         pl = net.project_layer
@@ -50,14 +50,23 @@ class GraphedRootNet:
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             if time_unprojection:
-                self._t0 = torch.cuda.Event(enable_timing=True, external=True)
-                self._t1 = torch.cuda.Event(enable_timing=True, external=True)
+                # three one-thread kernels that write the chip-wide 100 MHz clock: before and after get_voxel, and a third
+                # right behind the second (stamp-to-stamp distance with nothing in between = what the marker nodes cost)
+                import ctypes as C
+                lib = _lib.load()
+                lib.sp3d_debug_stamp.restype = C.c_int
+                lib.sp3d_debug_stamp.argtypes = [C.c_void_p, C.c_void_p]
+                self._stamps = torch.zeros(3, dtype=torch.int64, device=dev)
                 inner = pl.get_voxel
 
+                def stamp(i):
+                    _lib.check(lib.sp3d_debug_stamp(self._stamps[i:].data_ptr(), _lib._stream(dev)), "sp3d_debug_stamp")
+
                 def timed_get_voxel(*a, **k):
-                    self._t0.record()
+                    stamp(0)
                     r = inner(*a, **k)
-                    self._t1.record()
+                    stamp(1)
+                    stamp(2)
                     return r
                 pl.get_voxel = timed_get_voxel          # instance attribute: shadows the method while capturing only
             try:
@@ -72,12 +81,14 @@ class GraphedRootNet:
         self._plan = getattr(getattr(net, "v2v_net", None), "_plan", None)
         self._plan_tensors = dict(self._plan.t) if self._plan is not None else None     # incl. the padded FFT buffers
 
-    def unprojection_ms(self) -> float:
-        """time between the two event nodes of the LAST replay (``time_unprojection=True``); synchronises"""
-        if self._t0 is None:
+    def unprojection_us(self):
+        """(stamp before -> stamp after get_voxel, stamp -> adjacent stamp) of the LAST replay, microseconds
+        (``time_unprojection=True``); the kernel's time in the step is the first minus the second.  Synchronises."""
+        if self._stamps is None:
             raise RuntimeError("GraphedRootNet was not built with time_unprojection=True")
         torch.cuda.synchronize(self._dev)
-        return float(self._t0.elapsed_time(self._t1))
+        t = self._stamps.cpu().tolist()
+        return (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0
 
     def _stage(self, meta):
         """camera table of the NEXT fetch launch -> its ring slot (waits only if the GPU is RING launches behind)"""
