@@ -44,7 +44,25 @@ def _loop_reference(x, group_of, G, weight, bias, relu, dims, momentum=0.1, eps=
 
 
 def _rel(a, b):
-    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-300))
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-300))
+
+
+def _worst_param_grad(net_ref, net_got, floor):
+    """largest gradient error over the parameters, each relative to max(its own largest reference gradient, floor x the
+    largest gradient of the net): a convolution bias in front of a BatchNorm has an analytically ZERO gradient (the layer
+    removes the mean) - what both runs hold there is rounding noise, not a number to compare"""
+    pairs = [(n, pl.grad, po.grad) for (n, pl), (_, po) in zip(net_ref.named_parameters(), net_got.named_parameters())
+             if pl.grad is not None]
+    top = max(float(gl.detach().double().abs().max()) for _, gl, _ in pairs)
+    worst, where = 0.0, None
+    for n, gl, go in pairs:
+        assert go is not None, n
+        gl, go = gl.detach().double(), go.detach().double()
+        e = float((go - gl).abs().max() / max(float(gl.abs().max()), floor * top))
+        if e > worst:
+            worst, where = e, n
+    return worst, where
 
 
 CASES = [
@@ -177,10 +195,8 @@ def test_v2vnet_all_slots_in_one_call_equals_the_per_slot_loop_float64(dev):
         yo = one_net(x.contiguous(memory_format=torch.channels_last_3d))
     (yo * gy).sum().backward()
     assert _rel(yo, yl) <= 1e-9
-    worst = 0.0
-    for (name, pl), (_, po) in zip(loop_net.named_parameters(), one_net.named_parameters()):
-        worst = max(worst, _rel(po.grad, pl.grad))
-    assert worst <= 1e-7, worst
+    worst, where = _worst_param_grad(loop_net, one_net, 1e-6)
+    assert worst <= 1e-7, (worst, where)
     for (name, bl), (_, bo) in zip(loop_net.named_buffers(), one_net.named_buffers()):
         if name.endswith("num_batches_tracked"):
             assert int(bl) == int(bo) == 3, name
@@ -242,9 +258,8 @@ def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
             assert int(bl) == int(bo) == 3 * ssv_sets, name
         else:
             assert _rel(bo, bl) <= 1e-3, name
-    worst = max(_rel(po.grad, pl.grad) for (_, pl), (_, po) in zip(net_l.named_parameters(), net_o.named_parameters())
-                if pl.grad is not None and float(pl.grad.abs().max()) > 0)
-    assert worst <= 5e-2, worst
+    worst, where = _worst_param_grad(net_l, net_o, 1e-3)
+    assert worst <= 5e-2, (worst, where)
     # padding to a listed cube count: zero cubes in their own group change nothing
     net_p = copy.deepcopy(net_l)
     net_p.slot_pad_sizes = (8, 16)

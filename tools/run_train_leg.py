@@ -4,7 +4,7 @@ import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import bench
-a = argparse.Namespace(train_find="search", train_steps=int(os.environ.get("STEPS", 6)), train_warmup=int(os.environ.get("WARMUP", 3)), share_gpu=False)
+a = argparse.Namespace(train_find="search", train_steps=int(os.environ.get("STEPS", 6)), train_warmup=int(os.environ.get("WARMUP", 3)), share_gpu=False, legs_list=[])
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 print(json.dumps(bench.train_step_leg(a, 0, 1, dev)))
