@@ -785,6 +785,11 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.share_gpu:
+        # ranks that share a GPU load the library flavour without packed-fp32 instructions (libsp3d_nopk.so): the default
+        # flavour's unprojection arithmetic is wrong next to another plan's matrix instructions on the same CU
+        # (profiles/r05_shared_gpu.md).  Set before the first kernel call; inherited by the ranks self_launch starts.
+        os.environ["SP3D_SHARED_GPU"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -939,10 +944,13 @@ def main():
                            "what": "the timed K steps (= value) and further repeats of K steps on the same box, same rule"},
         }
         if args.share_gpu:
-            result["share_gpu_note"] = ("two inference plans on ONE GPU disturb each other (profiles/r04_gpu_sharing_finding.md): in this "
-                                        "smoke mode the output check is reported, not enforced; one process per GPU always passes it")
+            result["share_gpu_note"] = ("ranks that share a GPU run libsp3d_nopk.so (SP3D_SHARED_GPU=1: no packed-fp32 instructions), "
+                                        "which is immune to the matrix-instruction / packed-fp32 interaction of "
+                                        "profiles/r04_gpu_sharing_finding.md; the output check is ENFORCED (profiles/r05_shared_gpu.md)")
             result["config"]["parallelism"] = (f"SMOKE: {world} ranks share cuda:0, process group gloo (no RCCL): exercises the "
                                                f"multi-rank code path, not a scaling number")
+            from selfpose3d_amd import _lib as _l
+            result["config"]["library"] = os.path.basename(_l.LIB_PATH)
         if golden is not None and not args.no_check:
             result["output_check"] = check_output(out, golden)
         if not args.no_fp32_leg and not args.no_winograd and world == 1:
@@ -1022,7 +1030,7 @@ def main():
                 extra["unprojection_backward"] = {"error": f"{type(e).__name__}: {e}"}
         result["legs"] = extra
         print(json.dumps(result), flush=True)
-        if "output_check" in result and not result["output_check"]["ok"] and not args.share_gpu:
+        if "output_check" in result and not result["output_check"]["ok"]:
             raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")
     if world > 1:
         dist.barrier()

@@ -1118,6 +1118,16 @@ def test_winograd_fused_split64_kernel(shape):
     e, e3 = float((y.double() - ref).abs().max()), float((three.double() - ref).abs().max())
     assert e <= 5e-5 * max(1.0, float(ref.abs().max()))
     assert e <= 1.5 * e3 + 1e-7, (e, e3)
+    # round 5: the default is the wave-specialised kernel (one transform wave + two matrix waves per 16-channel chunk); the
+    # round-2 kernel (every wave builds its own operands) stays behind mode bit 8.  Same operands, same matrix instructions
+    # in the same order: bit-identical for C = 32 (two chunk groups in both); for C = 64 the four chunks' partial sums meet
+    # in another order ((c0 + c1) + c2 + c3 against (c0, c2) + (c1, c3)): last-bit differences only
+    old = _lib.wino_fused_conv3d_(x, U, shift, mode, res if mode >= 2 else None, U3, legacy16=True)
+    if C == 32:
+        assert torch.equal(y, old)
+    else:
+        eo = float((old.double() - ref).abs().max())
+        assert float((y - old).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max())) and e <= 1.25 * eo + 1e-7, (e, eo)
 
 
 @pytest.mark.gpu
