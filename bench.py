@@ -506,58 +506,7 @@ def unprojection_grids_leg(dev, iters=100):
         if c["bf16"]:
             event_time_ms(fn_planar, 100, dev)
             out[name]["kernel_us_planar_result"] = round(float(np.median([event_time_ms(fn_planar, iters, dev) for _ in range(3)])) * 1e3, 2)
-            # round 5: the same cubes gathered from FOOTPRINT records (one 128-byte line per voxel and view), and what
-            # building the records costs (once per batch of maps; here every cube has its own frame, the worst case)
-            foot = _lib.pack_footprint(packed)
-            fviews = [foot[i] for i in range(V)]
-            fn_f = lambda: _lib.unproject_fwd(fviews, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
-                                              channels_last=True, out_dtype=torch.bfloat16)
-            same = bool(torch.equal(fn_f()[0], fn()[0]))
-            event_time_ms(fn_f, 200, dev)
-            tf = float(np.median([event_time_ms(fn_f, iters, dev) for _ in range(3)]))
-            tp = float(np.median([event_time_ms(lambda: _lib.pack_footprint(packed), iters, dev) for _ in range(3)]))
-            out[name]["footprint_records"] = {
-                "kernel_us": round(tf * 1e3, 2), "frac": round(alg / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "producer_us": round(tp * 1e3, 2), "producer_bytes_written": int(foot.numel() * 2),
-                "bit_identical_to_pixel_maps": same,
-                "what": "unproject_brick_h_kernel<.., 8>: eight lanes per voxel read one 128-byte record = the 2x2 taps of 16 "
-                        "channels; producer = pack_footprint_kernel over ALL maps of the batch (here one frame per cube)"}
-            del foot, fviews
         del packed, views, hms
-    # configs[4] as an evaluation frame looks: 3 frames of a 4-view rig with 3-4 people each = ten 64^3 cubes that SHARE maps
-    try:
-        B, V, P = 3, 4, 10
-        cube, gs = syn.FINE_CUBE_SIZE, syn.FINE_GRID_SIZE
-        N = cube[0] * cube[1] * cube[2]
-        meta = syn.make_meta(B, V, img)
-        cam = torch.from_numpy(pack_cameras(meta, B, img)).to(dev)
-        rng = np.random.default_rng(1)
-        ctr = np.stack([rng.uniform(-1500, 1500, P), rng.uniform(-2000, 1000, P), rng.uniform(700, 1100, P)], 1)
-        centers = torch.from_numpy(ctr.astype(np.float32)).to(dev)
-        sample_of = torch.tensor([0, 0, 0, 1, 1, 1, 1, 2, 2, 2], dtype=torch.int32, device=dev)
-        valid = torch.ones(P, dtype=torch.uint8, device=dev)
-        hms = [x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=9)]
-        packed = _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16)
-        foot = _lib.pack_footprint(packed)
-        pv, fv = [packed[i] for i in range(V)], [foot[i] for i in range(V)]
-        run = lambda vs: _lib.unproject_fwd(vs, _lib.LAYOUT_NHWC, 16, cam, centers, valid, P, 16, h, w, cube, gs, img, False,
-                                            channels_last=True, out_dtype=torch.bfloat16, sample_of=sample_of)
-        same = bool(torch.equal(run(pv)[0], run(fv)[0]))
-        event_time_ms(lambda: run(pv), 200, dev)
-        t_p = float(np.median([event_time_ms(lambda: run(pv), iters, dev) for _ in range(3)]))
-        t_f = float(np.median([event_time_ms(lambda: run(fv), iters, dev) for _ in range(3)]))
-        t_mk = float(np.median([event_time_ms(lambda: _lib.pack_footprint(packed), iters, dev) for _ in range(3)]))
-        alg = 2.0 * (B * V * J * h * w + P * J * N)
-        out["configs4_3frames_10cubes_v4_bf16_shared_maps"] = {
-            "pixel_maps_us": round(t_p * 1e3, 2), "footprint_kernel_us": round(t_f * 1e3, 2), "footprint_producer_us": round(t_mk * 1e3, 2),
-            "footprint_total_us": round((t_f + t_mk) * 1e3, 2), "algorithmic_bytes": int(alg),
-            "frac_pixel_maps": round(alg / (t_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "frac_footprint_total": round(alg / ((t_f + t_mk) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bit_identical": same,
-            "what": "ten 64^3 cubes of 3 frames (3 + 4 + 3 people), 4 views, bf16 maps and channels-last bf16 cubes: gather "
-                    "from 32-byte pixels against footprint records built once for the 3 frames (ProjectLayer.footprint = 'auto' picks the records here)"}
-        del packed, foot, hms
-    except Exception as e:
-        out["configs4_3frames_10cubes_v4_bf16_shared_maps"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         out["output_check"] = unprojection_grids_check(dev)
     except Exception as e:

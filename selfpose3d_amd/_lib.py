@@ -22,7 +22,6 @@ LAYOUT_NHWC = 1
 OUT_CHANNELS_LAST = 0x100
 HM_BF16 = 0x200
 OUT_BF16 = 0x400
-HM_FOOTPRINT = 0x800
 SCATTER_AUTO, SCATTER_PER_TAP, SCATTER_MERGE = 0, 2, 3      # include/sp3d.h: per-call scatter choice of unproject_bwd_packed
 MAX_VIEWS = 16
 MAX_TOPK = 32
@@ -32,7 +31,7 @@ EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
     "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
-    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_pack_footprint", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
+    "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
 ]
 
 _lib = None
@@ -182,29 +181,6 @@ def pack_heatmaps(hms: Sequence[torch.Tensor], jp: int = 16, out: Optional[torch
     return out
 
 
-def pack_footprint(packed: torch.Tensor) -> torch.Tensor:
-    """packed bf16 maps (V,B,h,w,16) -> footprint records (V,B,h,w,64) bf16 (include/sp3d.h SP3D_HM_FOOTPRINT): per tap origin
-    the 2x2 block of all 16 channels in one 128-byte cache line.  Hand ``[foot[c] for c in range(V)]`` to unproject_fwd."""
-    lib = load()
-    _require_cuda(packed, "packed")
-    if packed.dtype != torch.bfloat16 or packed.dim() != 5 or packed.shape[-1] != 16 or not packed.is_contiguous():
-        raise Sp3dError("pack_footprint: a contiguous (V,B,h,w,16) bfloat16 buffer (pack_heatmaps(..., out_dtype=torch.bfloat16))")
-    V, B, h, w, _ = packed.shape
-    foot = torch.empty((V, B, h, w, 64), dtype=torch.bfloat16, device=packed.device)
-    lib.sp3d_pack_footprint.restype = C.c_int
-    lib.sp3d_pack_footprint.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    check(lib.sp3d_pack_footprint(packed.data_ptr(), foot.data_ptr(), int(B), int(V), int(h), int(w), _stream(packed.device)),
-          "sp3d_pack_footprint")
-    return foot
-
-
-def _hm_flags(views) -> int:
-    """storage flags of the heat-map views: bf16 pixels (…,16) or footprint records (…,64)"""
-    if views[0].dtype != torch.bfloat16:
-        return 0
-    return HM_FOOTPRINT if int(views[0].shape[-1]) == 64 else HM_BF16
-
-
 def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torch.Tensor, centers: torch.Tensor,
                   valid: torch.Tensor, B: int, J: int, h: int, w: int, cube_size, grid_size, img_size,
                   want_grids: bool = True, variant: Optional[int] = None, channels_last: bool = False,
@@ -223,7 +199,7 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
     if out is not None:
         assert layout == LAYOUT_NHWC and not channels_last and not want_grids and pass_mask is None and variant is None
         assert tuple(out.shape) == (B, J, X, Y, Z) and out.stride(4) == 1 and out.dtype == out_dtype
-        flags = _hm_flags(views) | (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
+        flags = (HM_BF16 if views[0].dtype == torch.bfloat16 else 0) | (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
         st = (C.c_int64 * 4)(*[int(v) for v in out.stride()[:4]])
         rc = lib.sp3d_unproject_fwd_strided(_ptr_array(views), layout | flags, jp, cam.data_ptr(),
                                             sample_of.data_ptr() if sample_of is not None else None, centers.data_ptr(),
@@ -235,7 +211,8 @@ def unproject_fwd(views: Sequence[torch.Tensor], layout: int, jp: int, cam: torc
         cubes = torch.empty((B, X, Y, Z, J), dtype=out_dtype, device=dev).permute(0, 4, 1, 2, 3)
     else:
         cubes = torch.empty((B, J, X, Y, Z), dtype=out_dtype, device=dev)
-    flags = (OUT_CHANNELS_LAST if channels_last else 0) | _hm_flags(views) | (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
+    flags = (OUT_CHANNELS_LAST if channels_last else 0) | (HM_BF16 if views[0].dtype == torch.bfloat16 else 0) | \
+        (OUT_BF16 if out_dtype == torch.bfloat16 else 0)
     grids = torch.empty((B, X * Y * Z, 3), dtype=torch.float32, device=dev) if want_grids else None
     gs = _f3(grid_size)
     if pass_mask is not None:

@@ -1500,7 +1500,7 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
         const dim3 sgrid((unsigned)blocks), sblock(192 * KS);
-#define SP3D_WS(C_, M_) { static bool attr_dev16s[64] = {}; bool &attr = attr_dev16s[dev]; if (!attr || dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused16s_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); if (ea != hipSuccess) return (int)ea; attr = true; } \
+#define SP3D_WS(C_, M_) { static bool attr_dev[64] = {}; bool &attr = attr_dev[dev]; if (!attr || dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused16s_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); if (ea != hipSuccess) return (int)ea; attr = true; } \
         hipLaunchKernelGGL((wino_fused16s_kernel<C_, M_>), sgrid, sblock, ldsb, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ); }
 #define SP3D_WSM(C_) switch (mode) { case 0: SP3D_WS(C_, 0); break; case 1: SP3D_WS(C_, 1); break; case 2: SP3D_WS(C_, 2); break; default: SP3D_WS(C_, 3); }
         if (C == 32) { SP3D_WSM(32) } else { SP3D_WSM(64) }

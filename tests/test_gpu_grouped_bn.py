@@ -210,17 +210,17 @@ def test_v2vnet_all_slots_in_one_call_equals_the_per_slot_loop_float64(dev):
 def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
     """PoseRegressionNet.forward_slots (one indexed unprojection per view set, one V2V pass, grouped BatchNorm) against the
     loop of PoseRegressionNet.forward calls in the reference's order: poses, heat-map gradients, running statistics"""
-    import copy
     from selfpose3d_amd import synthetic as syn
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd.pose_regression_net import PoseRegressionNet
     B, V, J, img, hm = 2, 3, 15, (128, 96), (32, 24)
     cfg = load_config(None, NETWORK__IMAGE_SIZE=list(img), NETWORK__HEATMAP_SIZE=list(hm), NETWORK__NUM_JOINTS=J,
                       PICT_STRUCT__CUBE_SIZE=[16, 16, 16])
-    net_l = PoseRegressionNet(cfg)
-    syn.fill_parameters_deterministic(net_l, seed=5, scale=0.08)
-    net_l.to(dev).train().use_channels_last(True)
-    net_o = copy.deepcopy(net_l)
+    def make():             # (no deepcopy: a ProjectLayer may hold device events)
+        net = PoseRegressionNet(cfg)
+        syn.fill_parameters_deterministic(net, seed=5, scale=0.08)
+        return net.to(dev).train().use_channels_last(True)
+    net_l, net_o = make(), make()
     sets_l, sets_o = [], []
     for s in range(ssv_sets):
         meta = syn.make_meta(B, V, img, rotations=[0.0, 20.0 * s], scale_mults=[1.0, 1.0 + 0.2 * s], ssv_style=True)
@@ -261,10 +261,8 @@ def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
     worst, where = _worst_param_grad(net_l, net_o, 1e-3)
     assert worst <= 5e-2, (worst, where)
     # padding to a listed cube count: zero cubes in their own group change nothing
-    net_p = copy.deepcopy(net_l)
+    net_p, net_q = make(), make()
     net_p.slot_pad_sizes = (8, 16)
-    net_q = copy.deepcopy(net_p)
-    net_q.slot_pad_sizes = None
     with torch.no_grad():
         pp = net_p.forward_slots([(sets_o[0][0], sets_o[0][1], sets_o[0][2])], gc)[0]
         pq = net_q.forward_slots([(sets_o[0][0], sets_o[0][1], sets_o[0][2])], gc)[0]

@@ -524,39 +524,6 @@ def test_bf16_storage_config(dev, V):
                                 cube, syn.FINE_GRID_SIZE, img, False, channels_last=True, out_dtype=torch.bfloat16)
     assert ccl.is_contiguous(memory_format=torch.channels_last_3d)
     assert torch.equal(ccl[:, :J].cpu(), ref16) and torch.count_nonzero(ccl[:, J:]) == 0
-    # round 5: footprint records (one 128-byte line per voxel and view) - the same bits in every output form, and several
-    # cubes per frame through ProjectLayer (records built once, shared)
-    foot = _lib.pack_footprint(packed)
-    assert foot.shape == (V, B, hm[1], hm[0], 64) and foot.dtype == torch.bfloat16
-    fv = [foot[c] for c in range(V)]
-    f32, _ = _lib.unproject_fwd(fv, _lib.LAYOUT_NHWC, 16, camd, cen, val, B, J, hm[1], hm[0], cube, syn.FINE_GRID_SIZE, img, False)
-    assert torch.equal(f32, c32)
-    f16, _ = _lib.unproject_fwd(fv, _lib.LAYOUT_NHWC, 16, camd, cen, val, B, J, hm[1], hm[0], cube, syn.FINE_GRID_SIZE, img, False,
-                                out_dtype=torch.bfloat16)
-    assert torch.equal(f16.cpu(), ref16)
-    fcl, _ = _lib.unproject_fwd(fv, _lib.LAYOUT_NHWC, 16, camd, cen, val, B, 16, hm[1], hm[0], cube, syn.FINE_GRID_SIZE, img, False,
-                                channels_last=True, out_dtype=torch.bfloat16)
-    assert torch.equal(fcl, ccl)
-    fcl32, _ = _lib.unproject_fwd(fv, _lib.LAYOUT_NHWC, 16, camd, cen, val, B, 16, hm[1], hm[0], cube, syn.FINE_GRID_SIZE, img, False,
-                                  channels_last=True)
-    assert torch.equal(fcl32[:, :J], c32) and torch.count_nonzero(fcl32[:, J:]) == 0
-    # record layout: chunk q of origin (x0, y0) = channels 2q, 2q+1 of the four pixels of the block; last row / column zero
-    pk = packed.cpu().float()
-    fr = foot.cpu().float().view(V, B, hm[1], hm[0], 8, 4, 2)
-    y0, x0 = 11, 37
-    for t, (dy, dx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-        assert torch.equal(fr[1, 1, y0, x0, :, t, :].reshape(16), pk[1, 1, y0 + dy, x0 + dx])
-    assert torch.count_nonzero(fr[:, :, -1]) == 0 and torch.count_nonzero(fr[:, :, :, -1]) == 0
-    layer.footprint = True
-    five = torch.tensor([[300.0, -800.0, 900.0], [-700.0, 100.0, 1000.0], [0.0, -500.0, 800.0], [900.0, 300.0, 950.0],
-                         [-200.0, -1500.0, 700.0]])
-    so = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32)
-    got, _ = layer.get_voxel([h.to(dev) for h in hms16], meta, syn.FINE_GRID_SIZE, five.to(dev), list(cube), sample_of=so.to(dev))
-    layer.footprint = False
-    want, _ = layer.get_voxel([h.to(dev) for h in hms16], meta, syn.FINE_GRID_SIZE, five.to(dev), list(cube), sample_of=so.to(dev))
-    assert torch.equal(got, want)
-    layer.footprint = "auto"                      # several 64^3 cubes per frame: records; one small cube per frame: pixels
-    assert layer.use_footprint(5, cube, B, hm[1], hm[0]) and not layer.use_footprint(2, (16, 16, 8), B, hm[1], hm[0])
 
 
 @pytest.mark.parametrize("name", ["unproj_grad_small", "unproj_grad_fine_aug"])
