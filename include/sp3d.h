@@ -90,13 +90,7 @@ enum {
      * (BASELINE configs[4] "mixed bf16": storage only - projection, interpolation and view fusion
      * stay fp32; cubes are rounded to nearest-even on the final store). */
     SP3D_HM_BF16 = 0x200,
-    SP3D_OUT_BF16 = 0x400,
-    /* OR-ed into hm_layout (NHWC, Jp == 16; implies bf16 storage of the maps): the view pointers address FOOTPRINT records
-     * built by sp3d_pack_footprint - per tap origin (x0, y0) of a view one 128-byte record holding the 2x2 block of all 16
-     * channels, i.e. (B, h, w, 64) bf16 per view.  A voxel's four bilinear taps are then ONE cache line per view instead
-     * of 2-4 (round 5; 4x the map bytes, written once per frame and shared by all person cubes).  Same results, bit for
-     * bit, as SP3D_HM_BF16.  Forward only. */
-    SP3D_HM_FOOTPRINT = 0x800
+    SP3D_OUT_BF16 = 0x400
 };
 
 int sp3d_abi_version(void);
@@ -198,11 +192,6 @@ enum {
     SP3D_SCATTER_PER_TAP = 2,
     SP3D_SCATTER_MERGE = 3
 };
-/* packed bf16 maps (V, B, h, w, 16) (sp3d_pack_heatmaps_ex with SP3D_HM_BF16) -> footprint records (V, B, h, w, 64) bf16
- * for SP3D_HM_FOOTPRINT; record (y0, x0), 16-byte chunk q = channels 2q, 2q+1 of the pixels (x0,y0) (x0+1,y0) (x0,y0+1)
- * (x0+1,y0+1); the records of the last row and column are zero (never addressed). */
-int sp3d_pack_footprint(const void *packed_bf16, void *footprint, int B, int V, int h, int w, void *stream);
-
 int sp3d_unproject_bwd_packed(const float *cam, const int32_t *sample_of, const float *centers, const uint8_t *valid,
                               const float *grad_cubes, const uint16_t *pass_mask, float *grad_packed, int B, int P,
                               int V, int J, int Jp, int h, int w, int X, int Y, int Z, const float *grid_size,

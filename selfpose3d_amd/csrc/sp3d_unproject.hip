@@ -851,23 +851,11 @@ __device__ __forceinline__ void bf16x8_to_f32(const uint4 r, float (&f)[8])
     f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 
-// LPV = lanes per voxel of a tap wave-load.
-//   LPV == 2 (round 4): bf16 pixels of 32 bytes, two lanes x 16 B; a view = 2 slots x 4 taps = 8 wave-loads of 32 voxels.
-//   LPV == 8 (round 5): FOOTPRINT records - per tap origin (x0, y0) one 128-byte record = the whole 2x2 footprint of all 16
-//     channels, channel-pair major: chunk q (16 B) = channels 2q, 2q+1 of the taps nw, ne, sw, se (pack_footprint_kernel).
-//     Eight lanes x 16 B = exactly ONE cache line per voxel and view (2-4 with pixel maps); a view = 8 slots = 8 wave-loads of
-//     8 voxels.  Same bytes into the registers, same number of wave-loads, 8 lines per wave-load instead of ~20: from the L2
-//     that is 83-92 cycles per 32 voxel-views against 150-195 (tools/tap_path_bench.hip, profiles/r05_tap_path_bench.txt).
-//     Each lane holds its 2 channels' four taps, so the interpolation chain needs no cross-lane traffic and is the SAME
-//     per-channel fp32 operation sequence: bit-identical results.
-template <int LPV>
 __device__ __forceinline__ void pipe_views_h(const Views &hm, const float *__restrict__ cam, const Geom &g, int bs, float x,
-                                             float y, float z, bool inb, float *ws, int lane, float (&acc)[LPV][16 / LPV],
+                                             float y, float z, bool inb, float *ws, int lane, float (&acc)[2][8],
                                              uint32_t &mymask)
 {
     constexpr int JP = 16;
-    constexpr int PIXB = LPV == 2 ? JP * 2 : 128;               // bytes per pixel / per footprint record
-    constexpr int VPL = 64 / LPV;                               // voxels per wave-load
     int *wsi = reinterpret_cast<int *>(ws);
     float4 *ws4 = reinterpret_cast<float4 *>(ws);
     const unsigned long long inbm = __builtin_amdgcn_ballot_w64(inb);
@@ -882,111 +870,60 @@ __device__ __forceinline__ void pipe_views_h(const Views &hm, const float *__res
         if (um == 0ull) return false;
         const RecPk r = make_record_pk(lane_of(um), st.i, g.w, g.h);
         const int v = (c & 1) * 64 + lane;
-        wsi[WOFF + v] = (int)__umul24((unsigned)PIXB, __umul24((unsigned)r.y0, (unsigned)g.w) + (unsigned)r.x0);     // bytes
+        wsi[WOFF + v] = (int)__umul24((unsigned)(JP * 2), __umul24((unsigned)r.y0, (unsigned)g.w) + (unsigned)r.x0);     // bytes
         ws4[v] = make_float4(r.wt.x, r.wt.y, r.wb.x, r.wb.y);
         return true;
     };
-    const int gv = lane / LPV, q = lane % LPV;
-    const uint32_t qoff = 16u * (uint32_t)q;                    // this lane's 16 bytes of the pixel / record
-    const size_t row_bytes = (size_t)g.w * PIXB;
+    const int g32 = lane >> 1, q = lane & 1;
+    const uint32_t qoff = 16u * (uint32_t)q;                    // this lane's 8 channels, bytes
+    const size_t row_bytes = (size_t)g.w * JP * 2;
     bool have = P1(0);
 #pragma unroll 1
     for (int c = 0; c < g.V; ++c) {
         const bool cur = have;
         const char *vb = reinterpret_cast<const char *>(hm.p[c]) + (size_t)bs * g.h * row_bytes;
         const char *vb2 = vb + row_bytes;
-        const int rb = (c & 1) * 64 + gv;
+        const int rb = (c & 1) * 64 + g32;
         if (cur) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (LPV == 2) {
-            uint4 t00[2], t10[2], t01[2], t11[2];
-            if (cur) {
+        uint4 t00[2], t10[2], t01[2], t11[2];
+        if (cur) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t off = (uint32_t)wsi[WOFF + rb + 32 * i] + qoff;
-                    t11[i] = *reinterpret_cast<const uint4 *>(vb2 + off + JP * 2);
-                    t01[i] = *reinterpret_cast<const uint4 *>(vb2 + off);
-                    t10[i] = *reinterpret_cast<const uint4 *>(vb + off + JP * 2);
-                    t00[i] = *reinterpret_cast<const uint4 *>(vb + off);
-                }
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t off = (uint32_t)wsi[WOFF + rb + 32 * i] + qoff;
+                t11[i] = *reinterpret_cast<const uint4 *>(vb2 + off + JP * 2);
+                t01[i] = *reinterpret_cast<const uint4 *>(vb2 + off);
+                t10[i] = *reinterpret_cast<const uint4 *>(vb + off + JP * 2);
+                t00[i] = *reinterpret_cast<const uint4 *>(vb + off);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
-            __builtin_amdgcn_sched_barrier(0);
-            if (cur) {
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < g.V) have = P1(c + 1);       // VALU work while the taps are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float4 wq = ws4[rb + 32 * i];                 // (w00, w10, w01, w11)
-                    float a[8], b[8], cc[8], d[8];
-                    bf16x8_to_f32(t00[i], a); bf16x8_to_f32(t10[i], b); bf16x8_to_f32(t01[i], cc); bf16x8_to_f32(t11[i], d);
+            for (int i = 0; i < 2; ++i) {
+                const float4 wq = ws4[rb + 32 * i];                 // (w00, w10, w01, w11)
+                float a[8], b[8], cc[8], d[8];
+                bf16x8_to_f32(t00[i], a); bf16x8_to_f32(t10[i], b); bf16x8_to_f32(t01[i], cc); bf16x8_to_f32(t11[i], d);
 #pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
-                        // ATen's bilinear chain per channel: fma(se, wse, fma(sw, wsw, fma(ne, wne, nw * wnw)))
-                        v2f v = v2f{a[k], a[k + 1]} * pk2(wq.x);
-                        v = pk_fma(v2f{b[k], b[k + 1]}, pk2(wq.y), v);
-                        v = pk_fma(v2f{cc[k], cc[k + 1]}, pk2(wq.z), v);
-                        v = pk_fma(v2f{d[k], d[k + 1]}, pk2(wq.w), v);
-                        const v2f s2 = v2f{acc[i][k], acc[i][k + 1]} + v;
-                        acc[i][k] = s2.x; acc[i][k + 1] = s2.y;
-                    }
-                }
-            }
-        } else {
-            (void)vb2;
-            uint4 t[LPV];
-            if (cur) {
-#pragma unroll
-                for (int i = 0; i < LPV; ++i)
-                    t[i] = *reinterpret_cast<const uint4 *>(vb + (uint32_t)wsi[WOFF + rb + VPL * i] + qoff);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < g.V) have = P1(c + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (cur) {
-#pragma unroll
-                for (int i = 0; i < LPV; ++i) {
-                    const float4 wq = ws4[rb + VPL * i];                // (w00, w10, w01, w11)
-                    const uint4 r = t[i];                               // (nw, ne, sw, se) of this lane's channel pair
-                    v2f v = v2f{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)} * pk2(wq.x);
-                    v = pk_fma(v2f{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)}, pk2(wq.y), v);
-                    v = pk_fma(v2f{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)}, pk2(wq.z), v);
-                    v = pk_fma(v2f{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)}, pk2(wq.w), v);
-                    const v2f s2 = v2f{acc[i][0], acc[i][1]} + v;
-                    acc[i][0] = s2.x; acc[i][1] = s2.y;
+                for (int k = 0; k < 8; k += 2) {
+                    // ATen's bilinear chain per channel: fma(se, wse, fma(sw, wsw, fma(ne, wne, nw * wnw)))
+                    v2f v = v2f{a[k], a[k + 1]} * pk2(wq.x);
+                    v = pk_fma(v2f{b[k], b[k + 1]}, pk2(wq.y), v);
+                    v = pk_fma(v2f{cc[k], cc[k + 1]}, pk2(wq.z), v);
+                    v = pk_fma(v2f{d[k], d[k + 1]}, pk2(wq.w), v);
+                    const v2f s2 = v2f{acc[i][k], acc[i][k + 1]} + v;
+                    acc[i][k] = s2.x; acc[i][k + 1] = s2.y;
                 }
             }
         }
     }
 }
 
-// producer of the footprint records: packed bf16 maps (V, B, h, w, 16) -> (V, B, h, w, 64) bf16, record (y0, x0) = the 2x2
-// block at origin (x0, y0), chunk q = channels 2q, 2q+1 of (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1); origins of the last
-// row / column (never addressed: make_record_pk clamps origins to [0, w-2] x [0, h-2]) are zero-filled.
-// One thread per (origin, chunk): four 4-byte reads (the 8 threads of an origin read 32 contiguous bytes per tap), one
-// 16-byte write.  Bytes: reads 4 x the map through L1 / L2, writes 4 x the map.
-__global__ __launch_bounds__(256) void pack_footprint_kernel(const uint32_t *__restrict__ packed, uint4 *__restrict__ foot,
-                                                            int h, int w, size_t planes)
-{
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;          // (plane, y0, x0, q)
-    const size_t per = (size_t)h * w * 8;
-    if (e >= planes * per) return;
-    const size_t pl = e / per;
-    const uint32_t r = (uint32_t)(e - pl * per);
-    const int q = (int)(r & 7u), px = (int)(r >> 3), y0 = px / w, x0 = px - y0 * w;
-    uint4 o = make_uint4(0u, 0u, 0u, 0u);
-    if (x0 < w - 1 && y0 < h - 1) {
-        const uint32_t *src = packed + (pl * h * w + (size_t)y0 * w + x0) * 8 + q;      // 8 dwords (16 bf16) per pixel
-        o.x = src[0];
-        o.y = src[8];
-        o.z = src[(size_t)w * 8];
-        o.w = src[(size_t)w * 8 + 8];
-    }
-    foot[e] = o;
-}
-
-template <bool OUTCL, typename TO, int LPV = 2>
+template <bool OUTCL, typename TO>
 __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_h_kernel(Views hm, const float *__restrict__ cam,
                                                                   const float *__restrict__ centers,
                                                                   const uint8_t *__restrict__ valid,
@@ -1014,8 +951,7 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_h_kernel
     const int vx = x0 + lx, vy = y0 + ly, vz = z0 + lz;
     const bool inb = vx < g.X && vy < g.Y && vz < g.Z;
     const int n = (min(vx, g.X - 1) * g.Y + min(vy, g.Y - 1)) * g.Z + min(vz, g.Z - 1);
-    constexpr int VPL = 64 / LPV, CPL = 16 / LPV;                  // voxels per wave-load, channels per lane
-    const int gv = lane / LPV, q = lane % LPV;
+    const int g32 = lane >> 1, q = lane & 1;
 
     if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
         if (inb) {
@@ -1040,60 +976,47 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_h_kernel
             gp[0] = x; gp[1] = y; gp[2] = z;
         }
         uint32_t mymask = 0;
-        float acc[LPV][CPL];
+        float acc[2][8];
 #pragma unroll
-        for (int i = 0; i < LPV; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) acc[i][k] = 0.0f;
-        pipe_views_h<LPV>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask);
+            for (int k = 0; k < 8; ++k) acc[i][k] = 0.0f;
+        pipe_views_h(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask);
 
         __builtin_amdgcn_wave_barrier();
         const float den_l = (float)(mymask & 0x7fffffffu) + 1e-6f;
         const float rden_l = (mymask & 0x80000000u) ? 0.0f : 1.0f / den_l;
 #pragma unroll
-        for (int i = 0; i < LPV; ++i) {
-            const int v = VPL * i + gv;                             // this slot's voxel inside the brick
+        for (int i = 0; i < 2; ++i) {
+            const int v = 32 * i + g32;                             // this slot's voxel inside the brick
             const float den = __shfl(den_l, v);
             const float rden = __shfl(rden_l, v);
             const bool bad = rden == 0.0f;
             const int gx = x0 + (v >> 4), gy = y0 + ((v >> 2) & 3), gz = z0 + (v & 3);
             const bool vin = gx < g.X && gy < g.Y && gz < g.Z;
             const int gn = (min(gx, g.X - 1) * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);
-            float o[CPL];
+            float o[8];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) o[k] = fuse_rcp(acc[i][k], den, rden);
+            for (int k = 0; k < 8; ++k) o[k] = fuse_rcp(acc[i][k], den, rden);
             if (g.pass_mask) {
                 uint32_t bits = 0;
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     const float pre = fuse_pre(acc[i][k], den, rden);
-                    if (!bad && pre >= 0.0f && pre <= 1.0f) bits |= 1u << (CPL * q + k);
+                    if (!bad && pre >= 0.0f && pre <= 1.0f) bits |= 1u << (8 * q + k);
                 }
-#pragma unroll
-                for (int m = 1; m < LPV; m <<= 1) bits |= (uint32_t)__shfl_xor((int)bits, m);
+                bits |= (uint32_t)__shfl_xor((int)bits, 1);
                 if (q == 0 && vin) g.pass_mask[(size_t)b * g.N + gn] = (uint16_t)bits;
             }
             if (OUTCL) {
                 if (vin) {
-                    TO *dst = cb + (size_t)gn * g.J + CPL * q;
-                    if constexpr (CPL == 8) {
-                        if (8 * q < g.J) Store4<TO>::store_nt(dst, make_float4(o[0], o[1], o[2], o[3]));
-                        if (8 * q + 4 < g.J) Store4<TO>::store_nt(dst + 4, make_float4(o[4], o[5], o[6], o[7]));
-                    } else if (CPL * q < g.J) {     // (J % 4 == 0 here) two channels per lane: the eight lanes of a voxel
-                        // write its 16 channels back to back, one 8-byte (fp32) / 4-byte (bf16) piece each
-                        if constexpr (sizeof(TO) == 4) {
-                            typedef float v2s __attribute__((ext_vector_type(2)));
-                            v2s t2; t2.x = o[0]; t2.y = o[1];
-                            __builtin_nontemporal_store(t2, reinterpret_cast<v2s *>(dst));
-                        } else {
-                            const uint32_t pk = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                            __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t *>(dst));
-                        }
-                    }
+                    TO *dst = cb + (size_t)gn * g.J + 8 * q;
+                    if (8 * q < g.J) Store4<TO>::store_nt(dst, make_float4(o[0], o[1], o[2], o[3]));
+                    if (8 * q + 4 < g.J) Store4<TO>::store_nt(dst + 4, make_float4(o[4], o[5], o[6], o[7]));
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) ws[(CPL * q + k) * WOSTR + v] = o[k];
+                for (int k = 0; k < 8; ++k) ws[(8 * q + k) * WOSTR + v] = o[k];
             }
         }
     }
@@ -1656,16 +1579,6 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
 #define SP3D_BRICK(CL_, TI_, TO_) \
     hipLaunchKernelGGL((unproject_brick_kernel<JP, CL_, TI_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
-        if (io & 4) {
-            // footprint records (bf16, 128 B per tap origin): eight lanes per voxel, one cache line per voxel and view
-            if (JP != 16 || !(io & 1)) return SP3D_EUNSUPPORTED;
-#define SP3D_BRICK_F(CL_, TO_) \
-    hipLaunchKernelGGL((unproject_brick_h_kernel<CL_, TO_, 8>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
-            if (io & 2) { if (out_cl) SP3D_BRICK_F(true, bf16_t); else SP3D_BRICK_F(false, bf16_t); }
-            else { if (out_cl) SP3D_BRICK_F(true, float); else SP3D_BRICK_F(false, float); }
-#undef SP3D_BRICK_F
-            return SP3D_OK;
-        }
         if ((io & 1) && JP == 16 && !((variant >> 9) & 1)) {
             // bf16 heat-maps: two lanes per pixel (tuning bit 9: keep the four-lane kernel below, for A/B)
 #define SP3D_BRICK_H(CL_, TO_) \
@@ -1777,10 +1690,6 @@ static int launch_nhwc(const Views &v, int Jp, const float *cam, const float *ce
     if ((int64_t)g.h * g.w > (1 << 24)) variant &= ~(8 | 32);    // the pipelined kernels form pixel indices with 24-bit multiplies
     variant &= ~128;                                             // (round-3 LDS patch kernels: measured slower, removed in round 4)
     if (variant & 32) variant |= 8;
-    if (io & 4) {                                                // footprint records exist for the brick kernel only
-        if (!(variant & 8) && (g.w < 2 || g.h < 2)) return SP3D_EUNSUPPORTED;
-        variant |= 32 | 8;
-    }
     if (io && !(variant & 8)) return SP3D_EUNSUPPORTED;
     if (io) variant |= 16;
     int rc;
@@ -1895,8 +1804,7 @@ extern "C" int sp3d_unproject_fwd_indexed(const float *const *hm_views, int hm_l
     hipStream_t s = (hipStream_t)stream;
     const int tiles = (g.N + TILE - 1) / TILE;
     const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
-    const int io = ((hm_layout & (SP3D_HM_BF16 | SP3D_HM_FOOTPRINT)) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0) |
-                   ((hm_layout & SP3D_HM_FOOTPRINT) ? 4 : 0);
+    const int io = ((hm_layout & SP3D_HM_BF16) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0);
     hm_layout &= 0xff;
     if (hm_layout == SP3D_LAYOUT_PLANAR) {
         if (out_cl || io) return SP3D_EUNSUPPORTED;
@@ -1923,8 +1831,7 @@ extern "C" int sp3d_unproject_fwd_strided(const float *const *hm_views, int hm_l
     if (rc) return rc;
     if (!cam || !centers || !valid || !cubes || !out_strides) return SP3D_ENULL;
     const bool out_cl = (hm_layout & SP3D_OUT_CHANNELS_LAST) != 0;
-    const int io = ((hm_layout & (SP3D_HM_BF16 | SP3D_HM_FOOTPRINT)) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0) |
-                   ((hm_layout & SP3D_HM_FOOTPRINT) ? 4 : 0);
+    const int io = ((hm_layout & SP3D_HM_BF16) ? 1 : 0) | ((hm_layout & SP3D_OUT_BF16) ? 2 : 0);
     if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || out_cl || w < 2 || h < 2) return SP3D_EUNSUPPORTED;
     const int64_t sB = out_strides[0], sJ = out_strides[1], sX = out_strides[2], sY = out_strides[3];
     // the planes must not overlap and must fit 32-bit in-plane offsets
@@ -2019,7 +1926,7 @@ extern "C" int sp3d_unproject_fwd_train(const float *const *hm_views, int hm_lay
     int rc = make_geom(g, P, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
     if (rc) return rc;
     if (!cam || !centers || !valid || !cubes || !pass_mask) return SP3D_ENULL;
-    if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || (hm_layout & (SP3D_HM_BF16 | SP3D_OUT_BF16 | SP3D_HM_FOOTPRINT)) || w < 2 || h < 2)
+    if ((hm_layout & 0xff) != SP3D_LAYOUT_NHWC || (hm_layout & (SP3D_HM_BF16 | SP3D_OUT_BF16)) || w < 2 || h < 2)
         return SP3D_EUNSUPPORTED;
     g.sample_of = sample_of;
     g.pass_mask = pass_mask;
@@ -2101,17 +2008,6 @@ extern "C" int sp3d_unproject_bwd_packed_det(const float *cam, const int32_t *sa
     if (!scale) return SP3D_ENULL;
     return bwd_packed_impl(cam, sample_of, centers, valid, grad_cubes, pass_mask, grad_fixed, scale, B, P, V, J, Jp, h, w, X,
                            Y, Z, grid_size, W_in, H_in, scatter, stream);
-}
-
-extern "C" int sp3d_pack_footprint(const void *packed_bf16, void *footprint, int B, int V, int h, int w, void *stream)
-{
-    if (B <= 0 || V <= 0 || V > SP3D_MAX_VIEWS || h < 2 || w < 2) return SP3D_EINVAL;
-    if (!packed_bf16 || !footprint) return SP3D_ENULL;
-    const size_t planes = (size_t)B * V, total = planes * h * w * 8;
-    if ((int64_t)h * w > (1 << 24) || (total + 255) / 256 > 0x7fffffffu) return SP3D_ERANGE;
-    hipLaunchKernelGGL(pack_footprint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint32_t *>(packed_bf16), reinterpret_cast<uint4 *>(footprint), h, w, planes);
-    return launch_status();
 }
 
 extern "C" int sp3d_fixed_to_float(const int64_t *acc, float *out, const float *scale, int64_t n, void *stream)

@@ -46,26 +46,8 @@ def packed_heatmaps(hms: Sequence[torch.Tensor], jp: int, dtype: torch.dtype = t
     return packed
 
 
-_FOOT_CACHE: "list[tuple]" = []
-
-
-def footprint_records(packed: torch.Tensor) -> torch.Tensor:
-    """footprint records of a packed bf16 buffer (``_lib.pack_footprint``), built once per buffer (weak reference + version
-    counter, as the re-tiling cache above): all person cubes of a frame gather from the same records"""
-    import weakref
-    for ref, version, foot in _FOOT_CACHE:
-        if ref() is packed and version == packed._version:
-            return foot
-    foot = _lib.pack_footprint(packed)
-    _FOOT_CACHE.append((weakref.ref(packed), packed._version, foot))
-    while len(_FOOT_CACHE) > 2:
-        _FOOT_CACHE.pop(0)
-    return foot
-
-
 def clear_pack_cache():
     _PACK_CACHE.clear()
-    _FOOT_CACHE.clear()
 
 
 def nhwc_heatmap_views(packed: torch.Tensor, num_joints: int) -> "list[torch.Tensor]":
@@ -122,9 +104,6 @@ class _UnprojectFn(torch.autograd.Function):
                 packed = _lib.pack_heatmaps(hms, jp=layer.jp_for(J), out_dtype=io)
             jp = packed.shape[-1]
             views = [packed[c] for c in range(len(hms))]
-            if io == torch.bfloat16 and jp == 16 and layer.use_footprint(B, cube_size, int(heatmaps[0].shape[0]), h, w):
-                foot = footprint_records(packed)          # one cache line per voxel and view instead of 2-4
-                views = [foot[c] for c in range(len(hms))]
             # when a gradient will be asked for, let the kernel also emit the clamp pass mask: the backward
             # then runs the line-coalesced scatter without re-reading any heat-map
             need_grad = io == torch.float32 and any(ctx.needs_input_grad[12:]) and w >= 2 and h >= 2
@@ -181,22 +160,11 @@ class ProjectLayer(nn.Module):
         self.heatmap_size = [int(v) for v in cfg.NETWORK.HEATMAP_SIZE]  # project_layer.py:20
         self.mode = mode
         self.cache_packs = True       # share the re-tiled heat-maps between the projections of one forward
-        # bf16 storage only: gather from FOOTPRINT records (include/sp3d.h SP3D_HM_FOOTPRINT: the 2x2 tap block of a pixel in
-        # one 128-byte line; built once per batch of maps, 4x their bytes).  "auto": when the cubes of the call hold at least
-        # 16 voxels per heat-map pixel (several person cubes per frame) - there the records' one line per voxel and view
-        # beats their production; True / False force it (tests, measurement)
-        self.footprint = "auto"
         self._cam_key = None
         self._cam_dev = None
         self._static_cam = None       # see static_camera_table()
         # gradient scatter in 64-bit fixed point (bit-identical run to run) instead of fp32 atomics; SP3D_BWD_DETERMINISTIC=1
         self.deterministic_backward = os.environ.get("SP3D_BWD_DETERMINISTIC", "0") not in ("", "0")
-
-    def use_footprint(self, cubes: int, cube_size, frames: int, h: int, w: int) -> bool:
-        if self.footprint != "auto":
-            return bool(self.footprint)
-        X, Y, Z = cube_size
-        return cubes * X * Y * Z >= 16 * frames * h * w
 
     @contextlib.contextmanager
     def static_camera_table(self, table: torch.Tensor):
