@@ -687,8 +687,7 @@ def wino_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: in
 
 
 def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mode: int,
-                       residual: Optional[torch.Tensor] = None, U3: Optional[torch.Tensor] = None,
-                       legacy16: bool = False) -> torch.Tensor:
+                       residual: Optional[torch.Tensor] = None, U3: Optional[torch.Tensor] = None) -> torch.Tensor:
     """one-launch Winograd 3x3x3 conv (C = 16 | 32 -> O = 32; with U3 also C = 32 | 64 -> O = 64) of channels_last_3d x
     with the fused epilogue; with U3 (wino_weights_split(U, 8 | 16)) the products run as exact three-piece bf16 splits
     on the bf16 matrix pipe"""
@@ -705,9 +704,8 @@ def wino_fused_conv3d_(x: torch.Tensor, U: torch.Tensor, shift: torch.Tensor, mo
         lib.sp3d_wino_fused_split64.restype = C.c_int
         lib.sp3d_wino_fused_split64.argtypes = [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]
         check(lib.sp3d_wino_fused_split64(x.data_ptr(), U3.data_ptr(), y.data_ptr(), shift.data_ptr(),
-                                          residual.data_ptr() if residual is not None else None,
-                                          int(mode) | (0x100 if legacy16 else 0),      # bit 8: the round-2 kernel (A/B, tests)
-                                          B, X, Y, Z, Cc, O, _stream(x.device)), "sp3d_wino_fused_split64")
+                                          residual.data_ptr() if residual is not None else None, int(mode), B, X, Y, Z, Cc, O,
+                                          _stream(x.device)), "sp3d_wino_fused_split64")
         return y
     if U3 is not None:
         lib.sp3d_wino_fused_split.restype = C.c_int

@@ -868,249 +868,6 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
 
 
 // ------------------------------------------------------------------------------------------
-// Round 5: the same layer with WAVE SPECIALISATION (wino_fused16s_kernel).
-//
-// In wino_fused16_kernel the two output-group waves of a channel group build the SAME A operands (region reads, y/z
-// transform, x transform, three-piece bf16 split: ~2/3 of the kernel's 10.9 k VALU instructions per wave) next to their own
-// matrix instructions, and the VALU is what bounds the kernel (0.21 matrix-pipe busy).  Here a channel group is THREE waves:
-//   T  (transform wave)   builds the operands of step s+1 once and leaves them in an LDS ring (two slots of 6 KB:
-//                         per x-transform index i one 16-byte [hi01 hi23 mid01 mid23] and one 8-byte [lo01 lo23] per lane);
-//   M0, M1 (matrix waves) read the operands of step s from the ring (their own lane's 24 dwords), stream their weights,
-//                         issue the 36 matrix instructions of the step and fold the y/z output transform into their
-//                         accumulators - 16 x NBW outputs each, exactly the arithmetic (and order) of wino_fused16_kernel.
-// One workgroup barrier per (y,z)-step.  Every channel group owns ONE 16-channel chunk (KS = C / 16 groups: 2 for C = 32, 4
-// for C = 64), so a region is staged once, by all three waves of its group, and nothing is prefetched across steps except the
-// matrix waves' weights (issued right before the barrier they wait at).  Workgroup = 3 * KS waves (6 | 12); LDS = KS x
-// (26.2 KB region + 12 KB ring) = 77 | 154 KB -> 2 | 1 workgroups per CU, 12 waves per CU either way (one T + two M per
-// SIMD: the T wave's VALU work overlaps the M waves' matrix instructions).  The KS partial sums meet in LDS at the end.
-// ------------------------------------------------------------------------------------------
-constexpr int W16S_I = 64 * 4 + 64 * 2;           // dwords per x-transform index in a ring slot: b128 + b64 per lane
-constexpr int W16S_SLOT = 4 * W16S_I;             // 1 536 dwords = 6 KB
-
-template <int C, int MODE>
-__global__ __launch_bounds__(192 * (C / 16)) __attribute__((amdgpu_waves_per_eu(3))) void wino_fused16s_kernel(
-    const float *__restrict__ x, const unsigned *__restrict__ U3, float *__restrict__ y, const float *__restrict__ shift,
-    const float *__restrict__ res, int B, int X, int Y, int Z, int NBX, int NBY, int NBZ)
-{
-    constexpr int O = 64, NCH = C / 16, KS = NCH, NBW = 2, NOW = 2, NTG = 192;
-    extern __shared__ __attribute__((aligned(16))) float lds16s[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool isT = wave < KS;
-    const int kg = isT ? wave : (wave - KS) % KS;                 // channel group = 16-channel chunk
-    const int ow = isT ? 0 : (wave - KS) / KS;                    // output group of a matrix wave
-    const int tg = (isT ? 0 : 1 + ow) * 64 + lane;                // thread index inside the channel group (staging)
-    float *region = lds16s + kg * W16_LDS;
-    unsigned *ring = reinterpret_cast<unsigned *>(lds16s + KS * W16_LDS) + kg * 2 * W16S_SLOT;
-    const int tl = lane & 15, q = lane >> 4;
-    int bid = blockIdx.x;
-    const int bz = bid % NBZ; bid /= NBZ;
-    const int by = bid % NBY; bid /= NBY;
-    const int bx = bid % NBX;
-    const int b = bid / NBX;
-    const int ttx = tl & 3, tty = tl >> 2;
-    const int ox0 = bx * 8, oy0 = by * 8, oz0 = bz * 2;
-    const float *rb = region + (2 * tty) * W16_ROW + (2 * ttx) * W16_VS + 4 * q;
-
-    // ---- the group's region: 400 voxels x 4 float4 of chunk kg, loaded once by the group's three waves
-    {
-        constexpr int NV4 = W16_RX * W16_RY * W16_RZ * 4, PER = (NV4 + NTG - 1) / NTG;
-        const float *xb = x + (int64_t)b * X * Y * Z * C + kg * 16;
-        float4 pre[PER];
-        int loff[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int idx = tg + u * NTG;
-            const int v = idx >> 2, part = idx & 3;
-            const int vx = v % W16_RX, vy = (v / W16_RX) % W16_RY, vz = v / (W16_RX * W16_RY);
-            const int gx = ox0 - 1 + vx, gy = oy0 - 1 + vy, gz = oz0 - 1 + vz;
-            const bool in = idx < NV4 && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
-            pre[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (in) pre[u] = *reinterpret_cast<const float4 *>(xb + ((((int64_t)gx) * Y + gy) * Z + gz) * C + part * 4);
-            loff[u] = idx < NV4 ? (vz * W16_RY + vy) * W16_ROW + vx * W16_VS + part * 4 : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-            if (loff[u] >= 0) *reinterpret_cast<float4 *>(region + loff[u]) = pre[u];
-    }
-
-    // T: operands of step jk -> ring slot
-    auto build = [&](int jk, unsigned *slot) {
-        const int j = jk >> 2, k = jk & 3;
-        const int ya = (j == 0) ? 0 : ((j == 2) ? 2 : 1), yb = (j == 3) ? 3 : ((j == 2) ? 1 : 2);
-        const int za = (k == 0) ? 0 : ((k == 2) ? 2 : 1), zb = (k == 3) ? 3 : ((k == 2) ? 1 : 2);
-        const float sy = (j == 1) ? 1.0f : -1.0f, sz = (k == 1) ? 1.0f : -1.0f;
-        const float *r00 = rb + (za * W16_RY + ya) * W16_ROW, *r10 = rb + (za * W16_RY + yb) * W16_ROW;
-        const float *r01 = rb + (zb * W16_RY + ya) * W16_ROW, *r11 = rb + (zb * W16_RY + yb) * W16_ROW;
-        float g[4][4];
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            const float4 v00 = *reinterpret_cast<const float4 *>(r00 + xi * W16_VS), v10 = *reinterpret_cast<const float4 *>(r10 + xi * W16_VS);
-            const float4 v01 = *reinterpret_cast<const float4 *>(r01 + xi * W16_VS), v11 = *reinterpret_cast<const float4 *>(r11 + xi * W16_VS);
-            g[xi][0] = fmaf(sz, fmaf(sy, v11.x, v01.x), fmaf(sy, v10.x, v00.x));
-            g[xi][1] = fmaf(sz, fmaf(sy, v11.y, v01.y), fmaf(sy, v10.y, v00.y));
-            g[xi][2] = fmaf(sz, fmaf(sy, v11.z, v01.z), fmaf(sy, v10.z, v00.z));
-            g[xi][3] = fmaf(sz, fmaf(sy, v11.w, v01.w), fmaf(sy, v10.w, v00.w));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float av[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                av[kk] = (i == 1) ? g[1][kk] + g[2][kk] : ((i == 3) ? g[3][kk] - g[1][kk] : g[wf_ta(i)][kk] - g[wf_tb(i)][kk]);
-            const unsigned hi01 = pack_bf16(av[0], av[1]), hi23 = pack_bf16(av[2], av[3]);
-            const float r0 = av[0] - bf16_lo(hi01), r1 = av[1] - bf16_hi(hi01), r2 = av[2] - bf16_lo(hi23), r3 = av[3] - bf16_hi(hi23);
-            const unsigned mid01 = pack_bf16(r0, r1), mid23 = pack_bf16(r2, r3);
-            const unsigned lo01 = pack_bf16(r0 - bf16_lo(mid01), r1 - bf16_hi(mid01));
-            const unsigned lo23 = pack_bf16(r2 - bf16_lo(mid23), r3 - bf16_hi(mid23));
-            *reinterpret_cast<u32x4 *>(slot + i * W16S_I + lane * 4) = u32x4{hi01, hi23, mid01, mid23};
-            *reinterpret_cast<u32x2 *>(slot + i * W16S_I + 256 + lane * 2) = u32x2{lo01, lo23};
-        }
-    };
-
-    __syncthreads();                               // the region is staged
-    if (isT) {
-        // ---- transform wave: one step ahead of its two matrix waves; same number of barriers as they execute
-        build(0, ring);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-        for (int jk = 0; jk < 16; ++jk) {
-            if (jk + 1 < 16) build(jk + 1, ring + ((jk + 1) & 1) * W16S_SLOT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_barrier();
-        }
-        __builtin_amdgcn_s_barrier();              // (the partial sums' barrier)
-        return;
-    }
-
-    // ---- matrix wave
-    f32x4 acc[8][NBW];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[a][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // weights of step jk (record of (point p = i*16 + jk, chunk kg, channel group q, output o): 6 dwords [mid hi lo])
-    const unsigned *ub = U3 + ((((int64_t)kg * 4 + q) * O) + ow * NBW * 16 + tl) * 6;
-    WfB bw[NBW][4];
-    auto load_w = [&](int jk) {
-#pragma unroll
-        for (int n = 0; n < NBW; ++n)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned *r = ub + (int64_t)(i * 16 + jk) * NCH * 4 * O * 6 + n * 16 * 6;
-                bw[n][i].mh = *reinterpret_cast<const u32x4_a8 *>(r);
-                bw[n][i].l = *reinterpret_cast<const u32x2_a8 *>(r + 4);
-            }
-    };
-    load_w(0);
-    __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-    for (int jk = 0; jk < 16; ++jk) {
-        const unsigned *slot = ring + (jk & 1) * W16S_SLOT;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int j = jk >> 2, k = jk & 3;
-        float cyz[4];
-#pragma unroll
-        for (int bc = 0; bc < 4; ++bc) {
-            const int bb = bc >> 1, c2 = bc & 1;
-            const float cy = bb == 0 ? (j < 3 ? 1.0f : 0.0f) : (j == 0 ? 0.0f : (j == 1 ? 1.0f : -1.0f));
-            const float cz = c2 == 0 ? (k < 3 ? 1.0f : 0.0f) : (k == 0 ? 0.0f : (k == 1 ? 1.0f : -1.0f));
-            cyz[bc] = cy * cz;
-        }
-        f32x4 M0[NBW], M1[NBW];
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) { M0[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; M1[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 hm = *reinterpret_cast<const u32x4 *>(slot + i * W16S_I + lane * 4);
-            const u32x2 lo = *reinterpret_cast<const u32x2 *>(slot + i * W16S_I + 256 + lane * 2);
-            const u32x4 Qhh = {hm.x, hm.y, hm.x, hm.y}, Qmm = {hm.z, hm.w, hm.z, hm.w}, Qlh = {lo.x, lo.y, hm.x, hm.y};
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) {
-                const WfB &w = bw[n][i];
-                const u32x4 Bmh = w.mh;
-                const u32x4 Bhl = {w.mh.z, w.mh.w, w.l.x, w.l.y};
-                if (i < 3) {
-                    M0[n] = mfma16_bf16(Qhh, Bmh, M0[n]);
-                    M0[n] = mfma16_bf16(Qmm, Bmh, M0[n]);
-                    M0[n] = mfma16_bf16(Qlh, Bhl, M0[n]);
-                }
-                if (i == 1 || i == 3) {
-                    M1[n] = mfma16_bf16(Qhh, Bmh, M1[n]);
-                    M1[n] = mfma16_bf16(Qmm, Bmh, M1[n]);
-                    M1[n] = mfma16_bf16(Qlh, Bhl, M1[n]);
-                }
-                if (i == 2) {
-                    const u32x4 nmh = Bmh ^ 0x80008000u, nhl = Bhl ^ 0x80008000u;
-                    M1[n] = mfma16_bf16(Qhh, nmh, M1[n]);
-                    M1[n] = mfma16_bf16(Qmm, nmh, M1[n]);
-                    M1[n] = mfma16_bf16(Qlh, nhl, M1[n]);
-                }
-            }
-        }
-        if (jk + 1 < 16) load_w(jk + 1);           // in flight while this wave folds and then waits for the transform wave
-#pragma unroll
-        for (int n = 0; n < NBW; ++n)
-#pragma unroll
-            for (int bc = 0; bc < 4; ++bc) {
-#if defined(SP3D_NO_PK)
-                for (int e = 0; e < 4; ++e) {
-                    acc[bc][n][e] = fmaf(M0[n][e], cyz[bc], acc[bc][n][e]);
-                    acc[4 + bc][n][e] = fmaf(M1[n][e], cyz[bc], acc[4 + bc][n][e]);
-                }
-#else
-                const f32x4 cv = {cyz[bc], cyz[bc], cyz[bc], cyz[bc]};
-                acc[bc][n] = __builtin_elementwise_fma(M0[n], cv, acc[bc][n]);
-                acc[4 + bc][n] = __builtin_elementwise_fma(M1[n], cv, acc[4 + bc][n]);
-#endif
-            }
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // partial sums of channel groups 1.. -> group 0, through LDS (regions and rings are free now)
-    f32x4 *red = reinterpret_cast<f32x4 *>(lds16s);
-    if (kg > 0) {
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) red[(((kg - 1) * NOW + ow) * 8 * NBW + a * NBW + n) * 64 + lane] = acc[a][n];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    if (kg > 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-    for (int g2 = 1; g2 < KS; ++g2)
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) acc[a][n] += red[(((g2 - 1) * NOW + ow) * 8 * NBW + a * NBW + n) * 64 + lane];
-
-#pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-        const int o = (ow * NBW + n) * 16 + tl;
-        const float sh = shift[o];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int tile = 4 * q + v;
-                const int rx = tile & 3, ry = tile >> 2;
-                const int xo = ox0 + 2 * rx + (a >> 2), yo = oy0 + 2 * ry + ((a >> 1) & 1), zo = oz0 + (a & 1);
-                if (xo < X && yo < Y && zo < Z) {
-                    const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o;
-                    float val = acc[a][n][v] + sh;
-                    if (MODE == 2) val += res[idx];
-                    if (MODE >= 1) val = fmaxf(val, 0.0f);
-                    if (MODE == 3) val += res[idx];
-                    y[idx] = val;
-                }
-            }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
 // Direct 3x3x3 convolution on the bf16 matrix pipe at fp32 accuracy (implicit GEMM, no Winograd).
 // With exact three-piece splits a multiply costs 3 bf16 MFMA slots, and the bf16 pipe is 16x the fp32 one: the 2.25x
 // multiplication saving of (x-folded) Winograd no longer pays for its operand transforms - the fused Winograd kernels
@@ -1476,11 +1233,10 @@ extern "C" int sp3d_wino_fused_split(const float *x, const void *U3, float *y, c
 }
 
 extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y, const float *shift, const float *residual,
-                                       int mode_in, int B, int X, int Y, int Z, int C, int O, void *stream)
+                                       int mode, int B, int X, int Y, int Z, int C, int O, void *stream)
 {
     using namespace sp3d;
-    const int mode = mode_in & 0xff;
-    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3 || (mode_in & ~0x1ff)) return SP3D_EINVAL;
+    if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || mode < 0 || mode > 3) return SP3D_EINVAL;
     if (!x || !U3 || !y || !shift || (mode >= 2 && !residual)) return SP3D_ENULL;
     if (O != 64 || (C != 32 && C != 64) || (reinterpret_cast<uintptr_t>(U3) & 7)) return SP3D_EUNSUPPORTED;
     const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 1) / 2;
@@ -1492,23 +1248,6 @@ extern "C" int sp3d_wino_fused_split64(const float *x, const void *U3, float *y,
     constexpr int nbw = 2, ks = 2;
     hipStream_t s = (hipStream_t)stream;
     const unsigned *u3 = reinterpret_cast<const unsigned *>(U3);
-    // round 5: the wave-specialised form (one transform wave + two matrix waves per 16-channel chunk).  mode bit 8
-    // (measurement / tests only) keeps the round-2 kernel for A/B
-    if (!(mode_in & 0x100)) {
-        const int KS = C / 16;
-        const size_t ldsb = (size_t)KS * (W16_LDS * sizeof(float) + 2 * W16S_SLOT * sizeof(unsigned));
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
-        const dim3 sgrid((unsigned)blocks), sblock(192 * KS);
-#define SP3D_WS(C_, M_) { static bool attr_dev[64] = {}; bool &attr = attr_dev[dev]; if (!attr || dev == 63) { hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused16s_kernel<C_, M_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); if (ea != hipSuccess) return (int)ea; attr = true; } \
-        hipLaunchKernelGGL((wino_fused16s_kernel<C_, M_>), sgrid, sblock, ldsb, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ); }
-#define SP3D_WSM(C_) switch (mode) { case 0: SP3D_WS(C_, 0); break; case 1: SP3D_WS(C_, 1); break; case 2: SP3D_WS(C_, 2); break; default: SP3D_WS(C_, 3); }
-        if (C == 32) { SP3D_WSM(32) } else { SP3D_WSM(64) }
-#undef SP3D_WSM
-#undef SP3D_WS
-        const hipError_t es = hipGetLastError();
-        return es == hipSuccess ? SP3D_OK : (int)es;
-    }
     const dim3 grid((unsigned)blocks), block(64 * (4 / nbw) * ks);
 #define SP3D_WF(C_, M_) hipLaunchKernelGGL((wino_fused16_kernel<C_, M_, 2, 2>), grid, block, 0, s, x, u3, y, shift, residual, B, X, Y, Z, NBX, NBY, NBZ)
 #define SP3D_WFM(C_) switch (mode) { case 0: SP3D_WF(C_, 0); break; case 1: SP3D_WF(C_, 1); break; case 2: SP3D_WF(C_, 2); break; default: SP3D_WF(C_, 3); }

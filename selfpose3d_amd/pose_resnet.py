@@ -29,8 +29,17 @@ def _view_coefficients(V: int, m: float, dtype, device) -> torch.Tensor:
     return _COEF[key]
 
 
-class ViewBatchNorm2d(nn.BatchNorm2d):
-    """BatchNorm2d that, in TRAIN mode with ``views = V > 1``, normalises an (B*V, C, H, W) batch stacked sample-major
+from .grouped_bn import GroupedBatchNorm2d, GroupSpec, bn_groups     # noqa: E402
+
+
+class ViewBatchNorm2d(GroupedBatchNorm2d):
+    """BatchNorm2d with per-view statistics for a backbone pass that holds ALL camera views.  Two mechanisms, same numbers:
+    * a ``GroupSpec`` attached (``grouped_bn.bn_groups``; round 5): the grouped channels-last HIP kernels
+      (``sp3d_gbn_forward`` / ``_backward``) with group_of[n] = n % V - what ``PoseResNet.forward_views`` uses on the GPU when
+      the backbone's weights are channels_last (the format its convolutions train fastest in: 43.3 against 51.1 ms forward +
+      backward for ten 512x960 images, tools/probe/backbone_format_probe.py), with the ReLU behind it fused;
+    * ``views = V > 1`` (round 4; plain NCHW tensors, any device): see below.
+    BatchNorm2d that, in TRAIN mode with ``views = V > 1``, normalises an (B*V, C, H, W) batch stacked sample-major
     (image n = b*V + v) with the statistics of EACH VIEW's B images separately - what the reference's per-view loop
     (`lib/models/multi_person_posenet.py:44-47`: one backbone call per camera) computes - in one pass: the contiguous batch
     viewed as (B, V*C, H, W) is a plain BatchNorm over V*C channels.  The running statistics receive the V sequential
@@ -40,8 +49,10 @@ class ViewBatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x):
         V = self.views
+        if self.groups is not None and self.training:
+            return self.grouped_forward(x, False)
         if V <= 1 or not self.training:
-            return super().forward(x)
+            return nn.BatchNorm2d.forward(self, x)
         N, C, H, W = x.shape
         if N % V or self.momentum is None or not self.track_running_stats:
             raise ValueError("ViewBatchNorm2d: batch must hold V views of every sample; momentum must be a number")
@@ -63,6 +74,14 @@ def _bn2(c):
     return ViewBatchNorm2d(c, momentum=_BN_MOM)
 
 
+def _bn_relu(bn, relu, x):
+    """relu(bn(x)); with a GroupSpec attached in train mode BatchNorm and ReLU are ONE pass (the ReLU's mask is recomputed
+    from the input in the backward, grouped_bn.py)"""
+    if getattr(bn, "groups", None) is not None and bn.training:
+        return bn.grouped_forward(x, relu=True)
+    return relu(bn(x))
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -76,7 +95,7 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        y = self.bn2(self.conv2(_bn_relu(self.bn1, self.relu, self.conv1(x))))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
 
 
@@ -95,8 +114,8 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
+        y = _bn_relu(self.bn1, self.relu, self.conv1(x))
+        y = _bn_relu(self.bn2, self.relu, self.conv2(y))
         y = self.bn3(self.conv3(y))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
 
@@ -154,9 +173,18 @@ class PoseResNet(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, x, attn: bool = False, head: bool = True):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn_relu(self.bn1, self.relu, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        feat = self.deconv_layers(x)
+        feat = x
+        mods = list(self.deconv_layers)
+        i = 0
+        while i < len(mods):                                  # (ConvTranspose2d, BatchNorm, ReLU) triples: BatchNorm + ReLU fused when grouped
+            if i + 2 < len(mods) and isinstance(mods[i + 1], ViewBatchNorm2d) and isinstance(mods[i + 2], nn.ReLU):
+                feat = _bn_relu(mods[i + 1], mods[i + 2], mods[i](feat))
+                i += 3
+            else:
+                feat = mods[i](feat)
+                i += 1
         out = self.final_layer(feat) if head else None
         return (out, feat) if attn else out
 
@@ -176,10 +204,20 @@ class PoseResNet(nn.Module):
             # ViewBatchNorm2d cannot address: such a backbone keeps the per-view loop (MultiPersonPoseNet.use_channels_last
             # leaves a training backbone in the plain format)
             bns = [m for m in self.modules() if isinstance(m, norm)]
-            if (not self.batch_views_in_training or V == 1 or not views[0].is_cuda or
-                    not self.conv1.weight.is_contiguous() or
-                    not all(isinstance(m, ViewBatchNorm2d) and m.training and m.track_running_stats and m.momentum is not None
-                            for m in bns)):
+            ours = all(isinstance(m, ViewBatchNorm2d) and m.training and m.track_running_stats and m.momentum is not None
+                       for m in bns)
+            cl_weights = not self.conv1.weight.is_contiguous()
+            if (self.batch_views_in_training and V > 1 and views[0].is_cuda and ours and cl_weights and
+                    views[0].dtype in (torch.float32, torch.float64)):
+                # round 5: channels_last weights (what the convolutions train fastest in) + the grouped channels-last
+                # BatchNorm kernels: image n = b * V + v belongs to group v; running statistics updated view 0 first
+                spec = GroupSpec([B] * V, views[0].device, group_of=[n % V for n in range(B * V)])
+                x = torch.stack(list(views), 1).flatten(0, 1).contiguous(memory_format=torch.channels_last)
+                with bn_groups(self, spec):
+                    y = self.forward(x)
+                y = y.view(B, V, *y.shape[1:])
+                return [y[:, v] for v in range(V)]
+            if (not self.batch_views_in_training or V == 1 or not views[0].is_cuda or cl_weights or not ours):
                 return [self.forward(v) for v in views]
             # one pass over all views with per-view BatchNorm statistics (ViewBatchNorm2d): the V x fewer, V x larger
             # kernels of the same arithmetic; gradients of the shared weights need no accumulation across calls
@@ -213,10 +251,12 @@ class PoseResNet(nn.Module):
 
 
 def set_backbone_memory_format(net: nn.Module, channels_last: bool) -> nn.Module:
-    """channels_last weights for a backbone (what MIOpen's NHWC kernels want) - except for a PoseResNet that is in train mode
-    and batches its views (``forward_views`` + ViewBatchNorm2d need the plain format)"""
-    batched_training = isinstance(net, PoseResNet) and net.training and net.batch_views_in_training
-    return net.to(memory_format=torch.channels_last if (channels_last and not batched_training) else torch.contiguous_format)
+    """channels_last weights for a backbone: what MIOpen's NHWC kernels want, in eval mode AND (round 5) in train mode - the
+    batched training pass keeps its per-view BatchNorm statistics through the grouped channels-last kernels
+    (``PoseResNet.forward_views``); a CPU backbone in train mode stays in the plain format (round 4's NCHW view trick)"""
+    on_gpu = next(net.parameters()).is_cuda
+    cpu_batched_training = isinstance(net, PoseResNet) and net.training and net.batch_views_in_training and not on_gpu
+    return net.to(memory_format=torch.channels_last if (channels_last and not cpu_batched_training) else torch.contiguous_format)
 
 
 class PoseResAttnNet(nn.Module):

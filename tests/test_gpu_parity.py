@@ -1085,16 +1085,6 @@ def test_winograd_fused_split64_kernel(shape):
     e, e3 = float((y.double() - ref).abs().max()), float((three.double() - ref).abs().max())
     assert e <= 5e-5 * max(1.0, float(ref.abs().max()))
     assert e <= 1.5 * e3 + 1e-7, (e, e3)
-    # round 5: the default is the wave-specialised kernel (one transform wave + two matrix waves per 16-channel chunk); the
-    # round-2 kernel (every wave builds its own operands) stays behind mode bit 8.  Same operands, same matrix instructions
-    # in the same order: bit-identical for C = 32 (two chunk groups in both); for C = 64 the four chunks' partial sums meet
-    # in another order ((c0 + c1) + c2 + c3 against (c0, c2) + (c1, c3)): last-bit differences only
-    old = _lib.wino_fused_conv3d_(x, U, shift, mode, res if mode >= 2 else None, U3, legacy16=True)
-    if C == 32:
-        assert torch.equal(y, old)
-    else:
-        eo = float((old.double() - ref).abs().max())
-        assert float((y - old).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max())) and e <= 1.25 * eo + 1e-7, (e, eo)
 
 
 @pytest.mark.gpu
@@ -1215,8 +1205,8 @@ def test_backbone_training_pass_batches_views_like_the_per_view_loop(monkeypatch
     the reference's loop over cameras (lib/models/multi_person_posenet.py:44-47).  In FLOAT64 on the GPU heat-maps, running
     statistics and every parameter's gradient agree to rounding (fp32 gradients through train-mode BatchNorm are
     ill-conditioned: the two passes use different convolution kernels and differ by percents there, as the reference's own
-    fp32 run does from its float64 rerun); in fp32 the heat-maps agree to 2e-4; a backbone whose weights
-    are channels_last keeps the loop"""
+    fp32 run does from its float64 rerun); in fp32 the heat-maps agree to 2e-4; the same for the
+    channels_last form of the pass (grouped BatchNorm kernels, round 5)"""
     import copy
     from selfpose3d_amd.config import load_config
     from selfpose3d_amd import pose_resnet as pr
@@ -1250,15 +1240,35 @@ def test_backbone_training_pass_batches_views_like_the_per_view_loop(monkeypatch
         for (n, p), q in zip(na.named_parameters(), nb.parameters()):
             g = float(q.grad.abs().max())
             assert float((p.grad - q.grad).abs().max()) <= grad_tol * max(g, 1e-30), (n, dt)
-    # channels_last weights: the per-view loop (no copies), same numbers again
-    b = copy.deepcopy(a)
-    b.batch_views_in_training = False
-    c = copy.deepcopy(b).to(memory_format=torch.channels_last)
-    c.batch_views_in_training = True
-    yb = b.forward_views(views)
-    scale = max(float(y.detach().abs().max()) for y in yb)
-    for u, w in zip(c.forward_views(views), yb):
-        assert float((u - w).detach().abs().max()) <= 2e-4 * scale
-    # the model-level switch leaves a training backbone in the plain format
-    assert pr.set_backbone_memory_format(a, True).conv1.weight.is_contiguous()
+    # round 5: channels_last weights = ONE pass through the grouped channels-last BatchNorm kernels (sp3d_gbn_*, ReLU fused),
+    # group of image n = n % V: float64 to rounding against the per-view loop (outputs, buffers, every gradient), fp32 to 2e-4
+    for dt, out_tol, grad_tol in ((torch.float64, 1e-9, 1e-7), (torch.float32, 2e-4, None)):
+        nb = copy.deepcopy(a).to(dt)
+        nb.batch_views_in_training = False
+        nc = copy.deepcopy(a).to(dt).to(memory_format=torch.channels_last)
+        assert nc.batch_views_in_training and not nc.conv1.weight.is_contiguous()
+        vv = [v.to(dt) for v in views]
+        calls = []
+        orig = nc.forward
+        nc.forward = lambda x, *a_, **k: (calls.append(tuple(x.shape)), orig(x, *a_, **k))[1]
+        yc, yb = nc.forward_views(vv), nb.forward_views(vv)
+        assert calls == [(B * V, 3, 128, 192)]                          # one pass over all views
+        assert all(m.groups is None for m in nc.modules() if isinstance(m, pr.ViewBatchNorm2d))      # spec detached again
+        scale = max(float(y.detach().abs().max()) for y in yb)
+        for u, w in zip(yc, yb):
+            assert u.shape == w.shape and float((u - w).detach().abs().max()) <= out_tol * scale, dt
+        for (n, u), w in zip(nc.named_buffers(), nb.buffers()):
+            assert torch.allclose(u.double(), w.double(), rtol=1e-4 if dt == torch.float32 else 1e-10,
+                                  atol=(1e-5 if dt == torch.float32 else 1e-11) * max(1.0, float(w.double().abs().max()))), (n, dt)
+        if grad_tol is None:
+            continue
+        sum((y * y).mean() for y in yc).backward()
+        sum((y * y).mean() for y in yb).backward()
+        top = max(float(q.grad.abs().max()) for q in nb.parameters())
+        for (n, p), q in zip(nc.named_parameters(), nb.parameters()):
+            g = max(float(q.grad.abs().max()), 1e-6 * top)
+            assert float((p.grad - q.grad).abs().max()) <= grad_tol * g, (n, dt)
+    # the model-level switch: channels_last for a GPU backbone in train and eval mode alike
+    assert not pr.set_backbone_memory_format(a, True).conv1.weight.is_contiguous()
     assert not pr.set_backbone_memory_format(a.eval(), True).conv1.weight.is_contiguous()
+    assert pr.set_backbone_memory_format(a, False).conv1.weight.is_contiguous()

@@ -146,9 +146,12 @@ def _child(args, tmp_path):
 
 
 def _train_step_child(tag, deterministic, batched=True):
-    """losses and gradients of one supervised train step against the reference's fp32 and float64 runs -> dict"""
+    """losses and gradients of one supervised train step against the reference's fp32 and float64 runs -> dict
+    (batched: 0 = per-camera loop, 1 = one NCHW pass, 2 = one channels_last pass through the grouped BatchNorm kernels - the
+    form tools/train_3d.py and the bench's train leg run)"""
     from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
     from selfpose3d_amd import pose_resnet
+    channels_last = int(batched) == 2
     pose_resnet.PoseResNet.batch_views_in_training = bool(batched)
     dev = torch.device("cuda:0")
     g = gio.load("train_step")
@@ -158,6 +161,8 @@ def _train_step_child(tag, deterministic, batched=True):
     model = get_multi_person_pose_net(cfg, is_train=True)
     gio.he_fill(model, seed=int(g["param_seed"]))
     model.to(dev).train()
+    if channels_last:
+        model.use_channels_last(True)
     for pl in (model.root_net.project_layer, model.pose_net.project_layer):
         pl.deterministic_backward = deterministic
     inputs, t2d, w2d, t3d, meta, _ = gio.train_batch(cfg, B=2, seed=int(g["data_seed"]))
@@ -219,13 +224,14 @@ GRAD_CAP = 0.1
 
 @pytest.mark.miopen_sensitive
 @pytest.mark.parametrize("deterministic", [False, True])
-@pytest.mark.parametrize("tag,views", [("net", "batched"), ("gt", "batched"), ("net", "loop"), ("gt", "loop")])
+@pytest.mark.parametrize("tag,views", [("net", "batched"), ("gt", "batched"), ("net", "loop"), ("gt", "loop"),
+                                       ("net", "batched_cl"), ("gt", "batched_cl")])
 def test_supervised_train_step_vs_reference(dev, tag, views, deterministic, tmp_path):
     """losses <= 1e-4 relative; gradients against the reference's fp32 AND float64 runs, with the scatter and the
     deterministic unprojection backward, with the backbone's views batched (default) and looped"""
-    if views == "loop" and deterministic:
+    if views != "batched" and deterministic:
         pytest.skip("the deterministic scatter is pinned with the default backbone pass")
-    rec = _child(["--train-step-child", tag, int(deterministic), int(views == "batched")], tmp_path)
+    rec = _child(["--train-step-child", tag, int(deterministic), {"loop": 0, "batched": 1, "batched_cl": 2}[views]], tmp_path)
     print(json.dumps(rec))
     assert rec["hm_sum_rel"] <= 1e-4 and rec["valid_equal"]
     for name in ("loss_2d", "loss_3d", "loss_cord"):
@@ -326,6 +332,6 @@ def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     if sys.argv[1] == "--train-step-child":
-        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])), bool(int(sys.argv[4])))))
+        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])), int(sys.argv[4]))))
     elif sys.argv[1] == "--ssv-step-child":
         print(json.dumps(_ssv_step_child(bool(int(sys.argv[2])))))
