@@ -20,6 +20,7 @@ WORKLOADS = {
     "coarse_b1_v5": dict(B=1, V=5, cube=syn.INITIAL_CUBE_SIZE, gs=syn.SPACE_SIZE, fine=False),
     "stress_b1_v10": dict(B=1, V=10, cube=(160, 160, 40), gs=syn.SPACE_SIZE, fine=False),
     "fine_b10_v5": dict(B=10, V=5, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),
+    "fine_b10_v4": dict(B=10, V=4, cube=syn.FINE_CUBE_SIZE, gs=syn.FINE_GRID_SIZE, fine=True),      # BASELINE configs[4]
 }
 
 
@@ -31,6 +32,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=1, help="number of distinct input sets cycled through")
     ap.add_argument("--planar", action="store_true")
     ap.add_argument("--cl", action="store_true", help="channels-last result (16 channels)")
+    ap.add_argument("--bf16", action="store_true", help="bf16 heat-maps and cubes (configs[4]: unproject_brick_h_kernel)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = WORKLOADS[args.workload]
@@ -48,7 +50,7 @@ def main():
     sets = []
     for r in range(args.rotate):
         hms = [x.to(dev) for x in syn.random_heatmaps(B, V, J, h, w, seed=7 + r)]
-        sets.append((hms, _lib.pack_heatmaps(hms, jp=16)))
+        sets.append((hms, _lib.pack_heatmaps(hms, jp=16, out_dtype=torch.bfloat16 if args.bf16 else torch.float32)))
     torch.cuda.synchronize()
     for it in range(args.iters):
         hms, packed = sets[it % args.rotate]
@@ -59,7 +61,7 @@ def main():
                                cube, gs, img, False, variant=None if args.variant < 0 else args.variant) if not args.cl else \
                 _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w,
                                    cube, gs, img, False, variant=None if args.variant < 0 else args.variant,
-                                   channels_last=True)
+                                   channels_last=True, out_dtype=torch.bfloat16 if args.bf16 else torch.float32)
     torch.cuda.synchronize()
     print("done", args.workload, args.variant, args.iters)
 
