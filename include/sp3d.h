@@ -403,8 +403,9 @@ int sp3d_upsample2x_scatter_head(const float *G, float *head, const float *shift
  * running_mean / running_var (NULL: none) receive the momentum updates of groups 0 .. G_update-1 IN THAT ORDER with the
  * unbiased variance - the sequence of updates the reference's loop makes (groups >= G_update, e.g. padding cubes, leave
  * them alone).  mean, invstd, scale, shift: (G, C) outputs, kept by the caller for the backward.
- * workspace: sp3d_gbn_workspace_bytes(G, C) bytes, ZERO-FILLED by the caller before EACH of the two calls (the
- * statistics merge with float64 atomics into SP3D_GBN_REPLICAS copies).
+ * workspace: sp3d_gbn_workspace_bytes(G, C) bytes, ZERO-FILLED by the caller ONCE: the statistics merge with float64
+ * atomics into SP3D_GBN_REPLICAS copies and the finalising kernel of each call zeroes them again, so forward and backward
+ * calls of any number of layers with the same (G, C) may share one workspace on one stream.
  * backward: dx = d loss / d x given dy = d loss / d y (with relu: dy counts only where y > 0, recomputed from x - y is not
  * needed); grad_weight, grad_bias (C) summed over all groups (NULL: skipped); k123: scratch of 3 * G * C elements.
  */

@@ -13,8 +13,10 @@
 //
 // Four streaming passes, all HBM-bound (16-byte accesses, a thread keeps its channel columns for all rows it visits):
 //   gbn_stats_kernel    x       -> per-(replica, group, channel) sum and sum of squares, accumulated in FLOAT64 per thread,
-//                                  merged with float64 memory atomics into R replicas (contention spread), caller-zeroed
-//   gbn_finalize_kernel         -> mean / invstd / scale / shift per (group, channel); running statistics (tiny)
+//                                  merged with float64 memory atomics into R = 16 replicas (contention spread)
+//   gbn_finalize_kernel         -> mean / invstd / scale / shift per (group, channel); running statistics; 16 lanes per
+//                                  channel reduce the replicas and ZERO them again (the workspace is zero-filled once, by
+//                                  the caller; every call leaves it zero-filled)
 //   gbn_apply_kernel    x       -> y = fma(x, scale, shift) [max 0]
 //   gbn_bwd_stats_kernel x, dy  -> sum dy, sum dy * xhat  (dy masked by the recomputed ReLU when fused)
 //   gbn_bwd_finalize_kernel     -> k1, k2, k3 per (group, channel); grad_weight, grad_bias
@@ -126,25 +128,55 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_stats_kernel(const T *__restrict_
     gbn_block_merge<W>(m, CV, s, q, acc + ((size_t)rep * G + g) * C * 2);
 }
 
-// one thread per channel; groups in order (the running statistics see the loop's sequence of momentum updates)
-template <typename T>
-__global__ __launch_bounds__(64) void gbn_finalize_kernel(const double *__restrict__ acc, const int32_t *__restrict__ group_samples,
-                                                          int64_t S, int C, int G, int R, int G_update,
-                                                          const T *__restrict__ weight, const T *__restrict__ bias,
-                                                          T *__restrict__ running_mean, T *__restrict__ running_var,
-                                                          double eps, double momentum, T *__restrict__ mean,
-                                                          T *__restrict__ invstd, T *__restrict__ scale, T *__restrict__ shift)
+// Sum of the R = 16 replicas of (group g, channel c): sixteen lanes per channel, one replica each, xor-shuffle reduction.
+// Every lane ZEROES the accumulator word it has read: the workspace is left zero-filled for the next call (the caller
+// fills it once).  Returns the totals in all sixteen lanes.
+constexpr int GBN_GB = 8;           // groups whose replica words are fetched together (independent loads, one latency)
+__device__ __forceinline__ void gbn_replica_fetch(double *__restrict__ acc, int G, int C, int g0, int c, int r, bool ok,
+                                                  double2 (&v)[GBN_GB])
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double w = weight ? (double)weight[c] : 1.0, b = bias ? (double)bias[c] : 0.0;
-    double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
-    for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
-        for (int r = 0; r < R; ++r) {
-            s += acc[(((size_t)r * G + g) * C + c) * 2 + 0];
-            q += acc[(((size_t)r * G + g) * C + c) * 2 + 1];
-        }
+#pragma unroll
+    for (int j = 0; j < GBN_GB; ++j) {
+        v[j] = make_double2(0.0, 0.0);
+        if (ok && g0 + j < G) v[j] = *reinterpret_cast<const double2 *>(acc + (((size_t)r * G + g0 + j) * C + c) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < GBN_GB; ++j)
+        if (ok && g0 + j < G) *reinterpret_cast<double2 *>(acc + (((size_t)r * G + g0 + j) * C + c) * 2) = make_double2(0.0, 0.0);
+}
+__device__ __forceinline__ void gbn_replica_sum(const double2 v, double &s, double &q)
+{
+    s = v.x; q = v.y;
+#pragma unroll
+    for (int m = 1; m < SP3D_GBN_REPLICAS; m <<= 1) {
+        s += __shfl_xor(s, m);
+        q += __shfl_xor(q, m);
+    }
+}
+
+// 256 threads = 16 channels x 16 replica lanes; groups in order (the running statistics see the loop's sequence of updates)
+template <typename T>
+__global__ __launch_bounds__(256) void gbn_finalize_kernel(double *__restrict__ acc, const int32_t *__restrict__ group_samples,
+                                                           int64_t S, int C, int G, int G_update,
+                                                           const T *__restrict__ weight, const T *__restrict__ bias,
+                                                           T *__restrict__ running_mean, T *__restrict__ running_var,
+                                                           double eps, double momentum, T *__restrict__ mean,
+                                                           T *__restrict__ invstd, T *__restrict__ scale, T *__restrict__ shift)
+{
+    static_assert(SP3D_GBN_REPLICAS == 16, "sixteen replica lanes per channel");
+    const int r = threadIdx.x & 15, c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = c < C;
+    const double w = (ok && weight) ? (double)weight[c] : 1.0, b = (ok && bias) ? (double)bias[c] : 0.0;
+    double rm = (ok && running_mean) ? (double)running_mean[c] : 0.0, rv = (ok && running_var) ? (double)running_var[c] : 0.0;
+    for (int g0 = 0; g0 < G; g0 += GBN_GB) {
+      double2 v[GBN_GB];
+      gbn_replica_fetch(acc, G, C, g0, c, r, ok, v);
+#pragma unroll
+      for (int j = 0; j < GBN_GB; ++j) {
+        const int g = g0 + j;
+        if (g >= G) break;
+        double s, q;
+        gbn_replica_sum(v[j], s, q);
         const double cnt = (double)group_samples[g] * (double)S;
         double mu = 0.0, var = 0.0;
         if (cnt > 0.0) {
@@ -155,18 +187,23 @@ __global__ __launch_bounds__(64) void gbn_finalize_kernel(const double *__restri
         const double is = 1.0 / sqrt(var + eps);
         // the T-rounded values are THE statistics: forward and backward both use them
         const T mu_t = (T)mu, is_t = (T)is;
-        mean[(size_t)g * C + c] = mu_t;
-        invstd[(size_t)g * C + c] = is_t;
-        const double sc = w * (double)is_t;
-        scale[(size_t)g * C + c] = (T)sc;
-        shift[(size_t)g * C + c] = (T)(b - (double)mu_t * sc);
+        if (ok && r == 0) {
+            mean[(size_t)g * C + c] = mu_t;
+            invstd[(size_t)g * C + c] = is_t;
+            const double sc = w * (double)is_t;
+            scale[(size_t)g * C + c] = (T)sc;
+            shift[(size_t)g * C + c] = (T)(b - (double)mu_t * sc);
+        }
         if (g < G_update && cnt > 1.0) {     // torch: running_var takes the UNBIASED batch variance
             rm = (1.0 - momentum) * rm + momentum * mu;
             rv = (1.0 - momentum) * rv + momentum * var * (cnt / (cnt - 1.0));
         }
+      }
     }
-    if (running_mean) running_mean[c] = (T)rm;
-    if (running_var) running_var[c] = (T)rv;
+    if (ok && r == 0) {
+        if (running_mean) running_mean[c] = (T)rm;
+        if (running_var) running_var[c] = (T)rv;
+    }
 }
 
 // grid (blocks, N): y = fma(x, scale[g], shift[g]) [max 0]; the (scale, shift) rows of the sample's group sit in LDS
@@ -252,36 +289,44 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_bwd_stats_kernel(const T *__restr
     gbn_block_merge<W>(m, CV, s, q, acc + ((size_t)rep * G + g) * C * 2);
 }
 
-// dx = w * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) = k1 * dy + k2 * x + k3
+// dx = w * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) = k1 * dy + k2 * x + k3   (16 channels x 16 replica lanes)
 template <typename T>
-__global__ __launch_bounds__(64) void gbn_bwd_finalize_kernel(const double *__restrict__ acc, const int32_t *__restrict__ group_samples,
-                                                              int64_t S, int C, int G, int R, const T *__restrict__ weight,
-                                                              const T *__restrict__ mean, const T *__restrict__ invstd,
-                                                              T *__restrict__ k1, T *__restrict__ k2, T *__restrict__ k3,
-                                                              T *__restrict__ grad_weight, T *__restrict__ grad_bias)
+__global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(double *__restrict__ acc, const int32_t *__restrict__ group_samples,
+                                                               int64_t S, int C, int G, const T *__restrict__ weight,
+                                                               const T *__restrict__ mean, const T *__restrict__ invstd,
+                                                               T *__restrict__ k1, T *__restrict__ k2, T *__restrict__ k3,
+                                                               T *__restrict__ grad_weight, T *__restrict__ grad_bias)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double w = weight ? (double)weight[c] : 1.0;
+    const int r = threadIdx.x & 15, c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = c < C;
+    const double w = (ok && weight) ? (double)weight[c] : 1.0;
     double gw = 0.0, gb = 0.0;
-    for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
-        for (int r = 0; r < R; ++r) {
-            s += acc[(((size_t)r * G + g) * C + c) * 2 + 0];
-            q += acc[(((size_t)r * G + g) * C + c) * 2 + 1];
-        }
+    for (int g0 = 0; g0 < G; g0 += GBN_GB) {
+      double2 v[GBN_GB];
+      gbn_replica_fetch(acc, G, C, g0, c, r, ok, v);
+#pragma unroll
+      for (int j = 0; j < GBN_GB; ++j) {
+        const int g = g0 + j;
+        if (g >= G) break;
+        double s, q;
+        gbn_replica_sum(v[j], s, q);
         gb += s;
         gw += q;
-        const double cnt = (double)group_samples[g] * (double)S;
-        const double is = (double)invstd[(size_t)g * C + c], mu = (double)mean[(size_t)g * C + c];
-        const double a = cnt > 0.0 ? s / cnt : 0.0, b = cnt > 0.0 ? q / cnt : 0.0;
-        const double c1 = w * is, c2 = -c1 * b * is;
-        k1[(size_t)g * C + c] = (T)c1;
-        k2[(size_t)g * C + c] = (T)c2;
-        k3[(size_t)g * C + c] = (T)(-c1 * a - c2 * mu);
+        if (ok && r == 0) {
+            const double cnt = (double)group_samples[g] * (double)S;
+            const double is = (double)invstd[(size_t)g * C + c], mu = (double)mean[(size_t)g * C + c];
+            const double a = cnt > 0.0 ? s / cnt : 0.0, b = cnt > 0.0 ? q / cnt : 0.0;
+            const double c1 = w * is, c2 = -c1 * b * is;
+            k1[(size_t)g * C + c] = (T)c1;
+            k2[(size_t)g * C + c] = (T)c2;
+            k3[(size_t)g * C + c] = (T)(-c1 * a - c2 * mu);
+        }
+      }
     }
-    if (grad_weight) grad_weight[c] = (T)gw;
-    if (grad_bias) grad_bias[c] = (T)gb;
+    if (ok && r == 0) {
+        if (grad_weight) grad_weight[c] = (T)gw;
+        if (grad_bias) grad_bias[c] = (T)gb;
+    }
 }
 
 template <typename T, bool RELU>
@@ -386,12 +431,12 @@ extern "C" int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t
     if (ab > cap) ab = cap;
     if (ab < 1) ab = 1;
     if (chunks > 0x7fffffff) return SP3D_ERANGE;
-    const dim3 gs((unsigned)chunks, (unsigned)N), ga((unsigned)ab, (unsigned)N), gf((unsigned)((C + 63) / 64));
+    const dim3 gs((unsigned)chunks, (unsigned)N), ga((unsigned)ab, (unsigned)N), gf((unsigned)((C + 15) / 16));
     if (dtype == SP3D_GBN_F32) {
         typedef float T;
         const size_t lds = 2 * (size_t)C * sizeof(T);
         hipLaunchKernelGGL(gbn_stats_kernel<T>, gs, dim3(GBN_TPB), 0, s, (const T *)x, group_of, S, C, G, R, rows, workspace);
-        hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(64), 0, s, workspace, group_samples, S, C, G, R, G_update,
+        hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, G_update,
                            (const T *)weight, (const T *)bias, (T *)running_mean, (T *)running_var, eps, momentum, (T *)mean,
                            (T *)invstd, (T *)scale, (T *)shift);
         if (relu) hipLaunchKernelGGL((gbn_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
@@ -400,7 +445,7 @@ extern "C" int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t
         typedef double T;
         const size_t lds = 2 * (size_t)C * sizeof(T);
         hipLaunchKernelGGL(gbn_stats_kernel<T>, gs, dim3(GBN_TPB), 0, s, (const T *)x, group_of, S, C, G, R, rows, workspace);
-        hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(64), 0, s, workspace, group_samples, S, C, G, R, G_update,
+        hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, G_update,
                            (const T *)weight, (const T *)bias, (T *)running_mean, (T *)running_var, eps, momentum, (T *)mean,
                            (T *)invstd, (T *)scale, (T *)shift);
         if (relu) hipLaunchKernelGGL((gbn_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
@@ -428,7 +473,7 @@ extern "C" int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dt
     if (ab > cap) ab = cap;
     if (ab < 1) ab = 1;
     if (chunks > 0x7fffffff) return SP3D_ERANGE;
-    const dim3 gs((unsigned)chunks, (unsigned)N), ga((unsigned)ab, (unsigned)N), gf((unsigned)((C + 63) / 64));
+    const dim3 gs((unsigned)chunks, (unsigned)N), ga((unsigned)ab, (unsigned)N), gf((unsigned)((C + 15) / 16));
     const size_t gc = (size_t)G * C;
 #define SP3D_GBN_BWD(T_)                                                                                                          \
     {                                                                                                                             \
@@ -437,7 +482,7 @@ extern "C" int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dt
         const size_t lds = 5 * (size_t)C * sizeof(T);                                                                             \
         if (relu) hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, true>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
         else hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, false>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
-        hipLaunchKernelGGL(gbn_bwd_finalize_kernel<T>, gf, dim3(64), 0, s, workspace, group_samples, S, C, G, R, (const T *)weight, (const T *)mean, (const T *)invstd, k1, k2, k3, (T *)grad_weight, (T *)grad_bias); \
+        hipLaunchKernelGGL(gbn_bwd_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, (const T *)weight, (const T *)mean, (const T *)invstd, k1, k2, k3, (T *)grad_weight, (T *)grad_bias); \
         if (relu) hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, S, C); \
         else hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, false>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, S, C); \
     }

@@ -1011,8 +1011,18 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_h_kernel
             if (OUTCL) {
                 if (vin) {
                     TO *dst = cb + (size_t)gn * g.J + 8 * q;
-                    if (8 * q < g.J) Store4<TO>::store_nt(dst, make_float4(o[0], o[1], o[2], o[3]));
-                    if (8 * q + 4 < g.J) Store4<TO>::store_nt(dst + 4, make_float4(o[4], o[5], o[6], o[7]));
+                    if (sizeof(TO) == 2 && 8 * q + 4 < g.J) {
+                        // bf16 cubes: the lane's 8 channels as ONE 16-byte store (round 5: two 8-byte pieces made the L2
+                        // write 136 MB for 84 MB of cubes, profiles/r05_pmc_configs4_bf16_v4.json)
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const uint2 lo = Store4<bf16_t>::pack4(make_float4(o[0], o[1], o[2], o[3]));
+                        const uint2 hi = Store4<bf16_t>::pack4(make_float4(o[4], o[5], o[6], o[7]));
+                        v4u t4; t4.x = lo.x; t4.y = lo.y; t4.z = hi.x; t4.w = hi.y;
+                        __builtin_nontemporal_store(t4, reinterpret_cast<v4u *>(dst));
+                    } else {
+                        if (8 * q < g.J) Store4<TO>::store_nt(dst, make_float4(o[0], o[1], o[2], o[3]));
+                        if (8 * q + 4 < g.J) Store4<TO>::store_nt(dst + 4, make_float4(o[4], o[5], o[6], o[7]));
+                    }
                 }
             } else {
 #pragma unroll

@@ -47,9 +47,29 @@ class GroupSpec:
         self._ws = {}
 
     def workspace(self, C_: int, device) -> torch.Tensor:
-        """zero-filled float64 (replicas, G, C, 2) accumulator (a fresh fill per call: the kernels add into it)"""
-        n = int(_lib.load().sp3d_gbn_workspace_bytes(self.G, int(C_))) // 8
-        return torch.zeros(n, dtype=torch.float64, device=device)
+        """float64 (replicas, G, C, 2) accumulator, zero-filled ONCE per (spec, C, stream): every forward / backward call
+        leaves it zero-filled again (include/sp3d.h), so all layers of that width share it in stream order"""
+        key = (int(C_), str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = int(_lib.load().sp3d_gbn_workspace_bytes(self.G, int(C_))) // 8
+            ws = self._ws[key] = torch.zeros(n, dtype=torch.float64, device=device)
+        return ws
+
+
+_SPECS: "dict[tuple, GroupSpec]" = {}
+
+
+def group_spec(sizes: Sequence[int], device, group_of: Optional[Sequence[int]] = None, n_update: Optional[int] = None) -> GroupSpec:
+    """a cached GroupSpec: a training loop presents the same few groupings step after step (5 views x B images; the slots of
+    a scene), and a spec owns device tensors and zero-filled workspaces that need not be rebuilt per step"""
+    key = (tuple(int(s) for s in sizes), None if group_of is None else tuple(int(g) for g in group_of), n_update, str(device))
+    spec = _SPECS.get(key)
+    if spec is None:
+        if len(_SPECS) >= 64:
+            _SPECS.pop(next(iter(_SPECS)))
+        spec = _SPECS[key] = GroupSpec(sizes, device, group_of=group_of, n_update=n_update)
+    return spec
 
 
 def _as_rows(x: torch.Tensor):

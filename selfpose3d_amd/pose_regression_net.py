@@ -122,7 +122,7 @@ class PoseRegressionNet(nn.Module):
         together and its grouped BatchNorm layers (grouped_bn.py) keep each call's statistics apart and update the running
         statistics call by call in the loop's order.  ``sets``: list of (all_heatmaps, meta, flip_xcoords);
         grid_centers (B,K,5); ``flags``: its column 3 on the host (saves the sync).  -> list of (B,K,J,3), one per set."""
-        from .grouped_bn import GroupSpec, bn_groups
+        from .grouped_bn import group_spec, bn_groups
         B, K = grid_centers.shape[:2]
         device = grid_centers.device
         J = sets[0][0][0].shape[1]
@@ -163,7 +163,7 @@ class PoseRegressionNet(nn.Module):
                 sizes = sizes + [target - total]
         if cl:
             x = x.contiguous(memory_format=torch.channels_last_3d)
-        spec = GroupSpec(sizes, device, group_of=group_of, n_update=n_update)
+        spec = group_spec(sizes, device, group_of=group_of, n_update=n_update)
         with bn_groups(self.v2v_net, spec):
             y = self.v2v_net(x)
         for si in range(ns):

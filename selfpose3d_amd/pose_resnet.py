@@ -29,7 +29,7 @@ def _view_coefficients(V: int, m: float, dtype, device) -> torch.Tensor:
     return _COEF[key]
 
 
-from .grouped_bn import GroupedBatchNorm2d, GroupSpec, bn_groups     # noqa: E402
+from .grouped_bn import GroupedBatchNorm2d, group_spec, bn_groups     # noqa: E402
 
 
 class ViewBatchNorm2d(GroupedBatchNorm2d):
@@ -67,7 +67,9 @@ class ViewBatchNorm2d(GroupedBatchNorm2d):
             self.running_mean.mul_(keep).add_(coef @ mean.view(V, C))
             self.running_var.mul_(keep).add_(coef @ var.view(V, C))
             self.num_batches_tracked += V
-        return torch.ops.aten._unsafe_view(y, (N, C, H, W))     # not an autograd view: the in-place ReLU behind it needs no CopySlices
+        # a plain (autograd) view: the in-place ReLU behind it then costs a CopySlices node, but nothing depends on whether a
+        # backend's batch_norm backward reads its saved output (round-4 advice; the fast path is the channels_last one above)
+        return y.view(N, C, H, W)
 
 
 def _bn2(c):
@@ -211,7 +213,7 @@ class PoseResNet(nn.Module):
                     views[0].dtype in (torch.float32, torch.float64)):
                 # round 5: channels_last weights (what the convolutions train fastest in) + the grouped channels-last
                 # BatchNorm kernels: image n = b * V + v belongs to group v; running statistics updated view 0 first
-                spec = GroupSpec([B] * V, views[0].device, group_of=[n % V for n in range(B * V)])
+                spec = group_spec([B] * V, views[0].device, group_of=[n % V for n in range(B * V)])
                 x = torch.stack(list(views), 1).flatten(0, 1).contiguous(memory_format=torch.channels_last)
                 with bn_groups(self, spec):
                     y = self.forward(x)
