@@ -241,6 +241,15 @@ int sp3d_soft_argmax(const float *x, const float *grids, float *out, int Bv, int
  * values compute_grid (project_layer.py:22-40) would have produced - instead of read from `grids` */
 int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
                           float *out, int Bv, int J, float beta, void *stream);
+/* the training pair of the same layer (autograd of pose_regression_net.py:19-28 w.r.t. the V2V output; the voxel centres carry
+ * no gradient): _train = sp3d_soft_argmax_grid that also keeps stats (Bv,J,2) = (max of beta x, sum of exp) per row, NULL
+ * allowed; _bwd: grad_x[b,j,n] = beta p_n (g . grid_n - g . out[b,j]) in ONE elementwise pass (read x, write grad_x), given
+ * out (Bv,J,3), stats and grad_out (Bv,J,3).  x, grad_x planar (Bv,J,X*Y*Z). */
+int sp3d_soft_argmax_grid_train(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z, float *out,
+                                float *stats, int Bv, int J, float beta, void *stream);
+int sp3d_soft_argmax_grid_bwd(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                              const float *out, const float *stats, const float *grad_out, float *grad_x, int Bv, int J,
+                              float beta, void *stream);
 
 /*
  * Fused inference epilogue for the V2V conv stack (BatchNorm folded into the conv weights by the

@@ -30,7 +30,7 @@ ABI_VERSION = 2
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_soft_argmax_grid_train", "sp3d_soft_argmax_grid_bwd", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
 ]
 
@@ -331,6 +331,56 @@ def soft_argmax_grid(x: torch.Tensor, centers: torch.Tensor, grid_size, cube_siz
     check(lib.sp3d_soft_argmax_grid(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(), P, J,
                                     float(beta), _stream(x.device)), "sp3d_soft_argmax_grid")
     return out
+
+
+class _SoftArgmaxGridFn(torch.autograd.Function):
+    """soft-argmax with in-kernel voxel centres under autograd (training pose net): forward = sp3d_soft_argmax_grid_train (also
+    keeps max and sum per row), backward = ONE elementwise pass (sp3d_soft_argmax_grid_bwd) instead of the softmax / product /
+    sum graph over a (P,J,N,3) temporary"""
+
+    @staticmethod
+    def forward(ctx, x, centers, grid_size, cube_size, beta):
+        lib = load()
+        _require_cuda(x, "x")
+        P, J = int(x.shape[0]), int(x.shape[1])
+        X, Y, Z = (int(c) for c in cube_size)
+        xc = x.detach().contiguous().float()                      # planar (P,J,N)
+        cc = centers.detach().contiguous().float()
+        out = torch.empty((P, J, 3), dtype=torch.float32, device=x.device)
+        stats = torch.empty((P, J, 2), dtype=torch.float32, device=x.device)
+        lib.sp3d_soft_argmax_grid_train.restype = C.c_int
+        lib.sp3d_soft_argmax_grid_train.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        check(lib.sp3d_soft_argmax_grid_train(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(),
+                                              stats.data_ptr(), P, J, float(beta), _stream(x.device)), "sp3d_soft_argmax_grid_train")
+        ctx.save_for_backward(xc, cc, out, stats)
+        ctx.geom = (tuple(float(v) for v in grid_size), (X, Y, Z), float(beta), x.is_contiguous(memory_format=torch.channels_last_3d)
+                    and not x.is_contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        xc, cc, out, stats = ctx.saved_tensors
+        grid_size, (X, Y, Z), beta, cl = ctx.geom
+        P, J = int(xc.shape[0]), int(xc.shape[1])
+        dx = torch.empty_like(xc)
+        gc = g.contiguous().float()
+        lib.sp3d_soft_argmax_grid_bwd.restype = C.c_int
+        lib.sp3d_soft_argmax_grid_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        check(lib.sp3d_soft_argmax_grid_bwd(xc.data_ptr(), cc.data_ptr(), _f3(grid_size), X, Y, Z, out.data_ptr(), stats.data_ptr(),
+                                            gc.data_ptr(), dx.data_ptr(), P, J, beta, _stream(xc.device)), "sp3d_soft_argmax_grid_bwd")
+        if cl:
+            dx = dx.contiguous(memory_format=torch.channels_last_3d)
+        return dx, None, None, None, None
+
+
+def soft_argmax_grid_autograd(x: torch.Tensor, centers: torch.Tensor, grid_size, cube_size, beta: float) -> torch.Tensor:
+    """x (P,J,X,Y,Z) fp32 (gradient flows to it), centers (P,3) -> (P,J,3)"""
+    if int(x.shape[0]) == 0:
+        return x.new_zeros((0, int(x.shape[1]), 3))
+    return _SoftArgmaxGridFn.apply(x, centers, grid_size, cube_size, beta)
 
 
 def fetch_ring(ring: torch.Tensor, dst: torch.Tensor, counter: torch.Tensor):

@@ -301,7 +301,8 @@ template <bool GRID>
 __global__ __launch_bounds__(SA_THREADS) void soft_argmax_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ grids,
                                                                 const float *__restrict__ centers, GridSpec gs,
-                                                                float *__restrict__ out, int J, int64_t N, float beta)
+                                                                float *__restrict__ out, int J, int64_t N, float beta,
+                                                                float *__restrict__ stats = nullptr)
 {
     __shared__ float red[4][SA_THREADS / 64];
     const int j = blockIdx.x, b = blockIdx.y;
@@ -346,6 +347,38 @@ __global__ __launch_bounds__(SA_THREADS) void soft_argmax_kernel(const float *__
         for (int w = 0; w < SA_THREADS / 64; ++w) { S += red[0][w]; A0 += red[1][w]; A1 += red[2][w]; A2 += red[3][w]; }
         float *o = out + ((size_t)b * J + j) * 3;
         o[0] = A0 / S; o[1] = A1 / S; o[2] = A2 / S;
+        if (stats) {            // (max of beta x, sum of exp): the backward pass needs no reduction of its own
+            stats[((size_t)b * J + j) * 2 + 0] = m;
+            stats[((size_t)b * J + j) * 2 + 1] = S;
+        }
+    }
+}
+
+// backward of the soft-argmax w.r.t. x (the voxel centres carry no gradient: proposals are detached):
+//   out_d = sum_n p_n grid_nd,  p_n = exp(beta x_n - m) / S   =>   dx_n = beta p_n (g . grid_n - g . out)
+// With (m, S) kept by the forward pass this is one elementwise pass: read x, write dx (8 bytes per element).
+__global__ __launch_bounds__(256) void soft_argmax_grid_bwd_kernel(const float *__restrict__ x, const float *__restrict__ centers,
+                                                                   GridSpec gs, const float *__restrict__ out,
+                                                                   const float *__restrict__ stats,
+                                                                   const float *__restrict__ grad_out, float *__restrict__ dx,
+                                                                   int J, int64_t N, float beta)
+{
+    const int j = blockIdx.y, b = blockIdx.z;
+    const size_t bj = (size_t)b * J + j;
+    const float m = stats[bj * 2], rS = 1.0f / stats[bj * 2 + 1];
+    const float g0 = grad_out[bj * 3], g1 = grad_out[bj * 3 + 1], g2 = grad_out[bj * 3 + 2];
+    const float go = g0 * out[bj * 3] + g1 * out[bj * 3 + 1] + g2 * out[bj * 3 + 2];
+    const float cx = centers[3 * b], cy = centers[3 * b + 1], cz = centers[3 * b + 2];
+    const int YZ = gs.Y * gs.Z;
+    const float *xv = x + bj * N;
+    float *dv = dx + bj * N;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const int nn = (int)n;
+        const int ix = nn / YZ, r = nn - ix * YZ, iy = r / gs.Z, iz = r - iy * gs.Z;
+        const float q0 = lin_at(gs.Lx, gs.sx, gs.X, ix) + cx, q1 = lin_at(gs.Ly, gs.sy, gs.Y, iy) + cy,
+                    q2 = lin_at(gs.Lz, gs.sz, gs.Z, iz) + cz;
+        const float p = __expf(beta * xv[n] - m) * rS;
+        dv[n] = beta * p * (fmaf(g0, q0, fmaf(g1, q1, g2 * q2)) - go);
     }
 }
 
@@ -412,13 +445,8 @@ extern "C" int sp3d_soft_argmax(const float *x, const float *grids, float *out, 
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
-extern "C" int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
-                                     float *out, int Bv, int J, float beta, void *stream)
+static GridSpec make_grid_spec(const float *grid_size, int X, int Y, int Z)
 {
-    if (Bv <= 0 || J <= 0 || X <= 0 || Y <= 0 || Z <= 0) return SP3D_EINVAL;
-    if (!x || !centers || !grid_size || !out) return SP3D_ENULL;
-    const int64_t N = (int64_t)X * Y * Z;
-    if (N > 0x7ffffffe) return SP3D_ERANGE;
     GridSpec gs;
     gs.X = X; gs.Y = Y; gs.Z = Z; gs.Lx = grid_size[0]; gs.Ly = grid_size[1]; gs.Lz = grid_size[2];
     const int n[3] = {X, Y, Z};
@@ -429,8 +457,42 @@ extern "C" int sp3d_soft_argmax_grid(const float *x, const float *centers, const
         st[a] = n[a] > 1 ? diff / (float)(n[a] - 1) : 0.0f;
     }
     gs.sx = st[0]; gs.sy = st[1]; gs.sz = st[2];
+    return gs;
+}
+
+extern "C" int sp3d_soft_argmax_grid_train(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                                           float *out, float *stats, int Bv, int J, float beta, void *stream)
+{
+    if (Bv <= 0 || J <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Bv > 65535) return SP3D_EINVAL;
+    if (!x || !centers || !grid_size || !out) return SP3D_ENULL;
+    const int64_t N = (int64_t)X * Y * Z;
+    if (N > 0x7ffffffe) return SP3D_ERANGE;
+    const GridSpec gs = make_grid_spec(grid_size, X, Y, Z);
     hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3(J, Bv), dim3(SA_THREADS), 0, (hipStream_t)stream, x,
-                       (const float *)nullptr, centers, gs, out, J, N, beta);
+                       (const float *)nullptr, centers, gs, out, J, N, beta, stats);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+extern "C" int sp3d_soft_argmax_grid(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                                     float *out, int Bv, int J, float beta, void *stream)
+{
+    return sp3d_soft_argmax_grid_train(x, centers, grid_size, X, Y, Z, out, nullptr, Bv, J, beta, stream);
+}
+
+extern "C" int sp3d_soft_argmax_grid_bwd(const float *x, const float *centers, const float *grid_size, int X, int Y, int Z,
+                                         const float *out, const float *stats, const float *grad_out, float *grad_x, int Bv,
+                                         int J, float beta, void *stream)
+{
+    if (Bv <= 0 || J <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Bv > 65535 || J > 65535) return SP3D_EINVAL;
+    if (!x || !centers || !grid_size || !out || !stats || !grad_out || !grad_x) return SP3D_ENULL;
+    const int64_t N = (int64_t)X * Y * Z;
+    if (N > 0x7ffffffe) return SP3D_ERANGE;
+    const GridSpec gs = make_grid_spec(grid_size, X, Y, Z);
+    int64_t nb = (N + 256 * 8 - 1) / (256 * 8);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(soft_argmax_grid_bwd_kernel, dim3((unsigned)nb, (unsigned)J, (unsigned)Bv), dim3(256), 0,
+                       (hipStream_t)stream, x, centers, gs, out, stats, grad_out, grad_x, J, N, beta);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

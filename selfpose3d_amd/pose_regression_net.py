@@ -148,9 +148,10 @@ class PoseRegressionNet(nn.Module):
         planar = self.v2v_net.wants_planar_input() and sets[0][0][0].is_cuda
         cl = self.channels_last and not planar
         cubes, grids = [], []
+        fused_sa = sets[0][0][0].dtype == torch.float32 and next(self.v2v_net.parameters()).dtype == torch.float32   # HIP pair: fp32
         for heatmaps, meta, flip in sets:
             c, g = self.project_layer.get_voxel(heatmaps, meta, self.grid_size, centers, self.cube_size, flip_xcoords=flip,
-                                                pad_channels=not planar, channels_last=cl, sample_of=bi)
+                                                want_grids=not fused_sa, pad_channels=not planar, channels_last=cl, sample_of=bi)
             cubes.append(c)
             grids.append(g)
         x = cubes[0] if ns == 1 else torch.cat(cubes, 0)
@@ -167,7 +168,12 @@ class PoseRegressionNet(nn.Module):
         with bn_groups(self.v2v_net, spec):
             y = self.v2v_net(x)
         for si in range(ns):
-            poses = self.soft_argmax_layer(y[si * P:(si + 1) * P], grids[si])            # (P,J,3)
+            ys = y[si * P:(si + 1) * P]
+            if fused_sa and ys.dtype == torch.float32:
+                # soft-argmax with in-kernel voxel centres, forward and backward as HIP kernels (no (P,J,N,3) temporary)
+                poses = _lib.soft_argmax_grid_autograd(ys, centers[:, :3], self.grid_size, self.cube_size, self.soft_argmax_layer.beta)
+            else:
+                poses = self.soft_argmax_layer(ys, grids[si])                            # (P,J,3)
             preds[si] = preds[si].index_put((bi, ki), poses)
         return preds
 

@@ -272,3 +272,32 @@ def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
             assert int(bq) == int(bp), name
         else:
             assert _rel(bp, bq) <= 1e-3, name
+
+
+def test_soft_argmax_training_pair_matches_the_torch_graph(dev):
+    """sp3d_soft_argmax_grid_train / _bwd (one workgroup per row forward keeping max and sum; one elementwise pass backward)
+    against SoftArgmaxLayer's torch graph (lib/models/pose_regression_net.py:19-28: softmax(beta x) . grid) in float64, on
+    planar and channels-last inputs; the voxel centres come from the unprojection kernel's own grids"""
+    from selfpose3d_amd import _lib, synthetic as syn
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.project_layer import ProjectLayer
+    P, J, cube, gs, beta = 3, 15, (16, 12, 10), (2000.0, 1800.0, 1500.0), 100.0
+    cfg = load_config(None, NETWORK__IMAGE_SIZE=[128, 96], NETWORK__HEATMAP_SIZE=[32, 24])
+    centers = torch.tensor([[100.0, -300.0, 900.0], [-700.0, 250.0, 1100.0], [0.0, 0.0, 800.0]], device=dev)
+    meta = syn.make_meta(1, 2, (128, 96))
+    hms = [h.to(dev) for h in syn.random_heatmaps(1, 2, J, 24, 32, seed=4)]
+    _, grids = ProjectLayer(cfg).get_voxel(hms, meta, list(gs), centers, list(cube), sample_of=torch.zeros(P, dtype=torch.int32))
+    gen = torch.Generator().manual_seed(12)
+    x0 = (torch.randn(P, J, *cube, generator=gen) * 0.03).to(dev)            # beta x of a few units: a soft maximum
+    wgt = torch.randn(P, J, 3, generator=gen).to(dev)
+    xd = x0.double().requires_grad_(True)
+    p = torch.softmax(beta * xd.reshape(P, J, -1, 1), dim=2)
+    ref = (p * grids.double().unsqueeze(1)).sum(dim=2)
+    (ref * wgt.double()).sum().backward()
+    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+        x = x0.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        out = _lib.soft_argmax_grid_autograd(x, centers, gs, cube, beta)
+        (out * wgt).sum().backward()
+        assert float((out.double() - ref).abs().max()) <= 2e-3                # mm, on a 2 m cube
+        assert _rel(x.grad, xd.grad) <= 2e-4
+        assert x.grad.shape == x.shape
