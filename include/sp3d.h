@@ -408,28 +408,34 @@ int sp3d_upsample2x_scatter_head(const float *G, float *head, const float *shift
  *   group_of       int32 (N): group of sample n, any assignment in [0, G)
  *   group_samples  int32 (G): number of samples in each group (0 allowed: statistics 0 / 1, never used)
  * per (group g, channel c), over the group's samples x S:  mean = E[x],  var = E[x^2] - mean^2 (float64 accumulation),
- *   y = (x - mean) / sqrt(var + eps) * weight + bias  [then max(0, .) if relu]
+ *   y = (x - mean) / sqrt(var + eps) * weight + bias                          mode SP3D_GBN_PLAIN (0)
+ *   y = max(0, that)                                                           mode SP3D_GBN_RELU (1)
+ *   y = max(0, that + residual)   (the tail of a residual block in one pass)   mode SP3D_GBN_ADD_RELU (2), residual (N, S, C)
  * running_mean / running_var (NULL: none) receive the momentum updates of groups 0 .. G_update-1 IN THAT ORDER with the
  * unbiased variance - the sequence of updates the reference's loop makes (groups >= G_update, e.g. padding cubes, leave
  * them alone).  mean, invstd, scale, shift: (G, C) outputs, kept by the caller for the backward.
  * workspace: sp3d_gbn_workspace_bytes(G, C) bytes, ZERO-FILLED by the caller ONCE: the statistics merge with float64
  * atomics into SP3D_GBN_REPLICAS copies and the finalising kernel of each call zeroes them again, so forward and backward
  * calls of any number of layers with the same (G, C) may share one workspace on one stream.
- * backward: dx = d loss / d x given dy = d loss / d y (with relu: dy counts only where y > 0, recomputed from x - y is not
- * needed); grad_weight, grad_bias (C) summed over all groups (NULL: skipped); k123: scratch of 3 * G * C elements.
+ * backward: dx = d loss / d x given dy = d loss / d y (mode 1: dy counts only where y > 0, recomputed from x - y is not
+ * needed; mode 2: where the forward's output `y` (N, S, C) is > 0, and grad_residual (N, S, C) receives that masked dy);
+ * grad_weight, grad_bias (C) summed over all groups (NULL: skipped); k123: scratch of 3 * G * C elements.
  */
 #define SP3D_GBN_F32 0
 #define SP3D_GBN_F64 1
 #define SP3D_GBN_REPLICAS 16
+#define SP3D_GBN_PLAIN 0
+#define SP3D_GBN_RELU 1
+#define SP3D_GBN_ADD_RELU 2
 int64_t sp3d_gbn_workspace_bytes(int G, int C);
 int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t *group_of, const int32_t *group_samples, int N,
                      int64_t S, int C, int G, int G_update, const void *weight, const void *bias, void *running_mean,
-                     void *running_var, double eps, double momentum, int relu, void *mean, void *invstd, void *scale,
-                     void *shift, double *workspace, void *stream);
+                     void *running_var, double eps, double momentum, int mode, const void *residual, void *mean,
+                     void *invstd, void *scale, void *shift, double *workspace, void *stream);
 int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dtype, const int32_t *group_of,
                       const int32_t *group_samples, int N, int64_t S, int C, int G, const void *weight, const void *mean,
-                      const void *invstd, const void *scale, const void *shift, int relu, void *grad_weight,
-                      void *grad_bias, void *k123, double *workspace, void *stream);
+                      const void *invstd, const void *scale, const void *shift, int mode, const void *y,
+                      void *grad_residual, void *grad_weight, void *grad_bias, void *k123, double *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -207,11 +207,14 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(double *__restrict__ 
 }
 
 // grid (blocks, N): y = fma(x, scale[g], shift[g]) [max 0]; the (scale, shift) rows of the sample's group sit in LDS
-template <typename T, bool RELU>
+// MODE 0: y = bn(x); 1: y = max(0, bn(x)); 2: y = max(0, bn(x) + residual)  (the tail of a residual block, v2v_net.py:42-45,
+// pose_resnet.py BasicBlock / Bottleneck: BatchNorm, add and ReLU in one pass)
+template <typename T, int MODE>
 __global__ __launch_bounds__(GBN_TPB) void gbn_apply_kernel(const T *__restrict__ x, const int32_t *__restrict__ group_of,
                                                             const T *__restrict__ scale, const T *__restrict__ shift,
-                                                            T *__restrict__ y, int64_t S, int C)
+                                                            const T *__restrict__ res, T *__restrict__ y, int64_t S, int C)
 {
+    constexpr bool RELU = MODE >= 1;
     constexpr int W = GbnVec<T>::W;
     typedef typename GbnVec<T>::V V;
     extern __shared__ __attribute__((aligned(16))) unsigned char gbn_smem[];
@@ -224,15 +227,18 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_apply_kernel(const T *__restrict_
     __syncthreads();
     const int64_t nv = S * CV, stride = (int64_t)gridDim.x * blockDim.x;
     const V *xp = reinterpret_cast<const V *>(x + (size_t)n * S * C);
+    const V *rp = MODE == 2 ? reinterpret_cast<const V *>(res + (size_t)n * S * C) : nullptr;
     V *yp = reinterpret_cast<V *>(y + (size_t)n * S * C);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const int col = (int)(i % CV);
-        T a[W], sc[W], sh[W];
+        T a[W], sc[W], sh[W], rr[W];
         GbnVec<T>::unpack(xp[i], a);
+        if (MODE == 2) GbnVec<T>::unpack(rp[i], rr);
         GbnVec<T>::unpack(*reinterpret_cast<const V *>(tab + col * W), sc);
         GbnVec<T>::unpack(*reinterpret_cast<const V *>(tab + C + col * W), sh);
         for (int e = 0; e < W; ++e) {
             a[e] = fma(a[e], sc[e], sh[e]);
+            if (MODE == 2) a[e] = a[e] + rr[e];
             if (RELU) a[e] = a[e] > (T)0 ? a[e] : (T)0;
         }
         yp[i] = GbnVec<T>::pack(a);
@@ -240,14 +246,17 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_apply_kernel(const T *__restrict_
 }
 
 // sum dy and sum dy * xhat per (replica, group, channel); with RELU dy counts only where fma(x, scale, shift) > 0
-template <typename T, bool RELU>
+// (MODE 2: dy counts where the block's OUTPUT y is positive - y is what the next layer kept anyway)
+template <typename T, int MODE>
 __global__ __launch_bounds__(GBN_TPB) void gbn_bwd_stats_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                                const T *__restrict__ yout,
                                                                 const int32_t *__restrict__ group_of,
                                                                 const T *__restrict__ mean, const T *__restrict__ invstd,
                                                                 const T *__restrict__ scale, const T *__restrict__ shift,
                                                                 int64_t S, int C, int G, int R, int64_t rows,
                                                                 double *__restrict__ acc)
 {
+    constexpr bool RELU = MODE == 1;
     constexpr int W = GbnVec<T>::W;
     typedef typename GbnVec<T>::V V;
     const int CV = C / W;
@@ -271,13 +280,16 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_bwd_stats_kernel(const T *__restr
             }
             const V *px = reinterpret_cast<const V *>(x + off) + col;
             const V *pd = reinterpret_cast<const V *>(dy + off) + col;
+            const V *py = MODE == 2 ? reinterpret_cast<const V *>(yout + off) + col : nullptr;
 #pragma unroll 2
             for (int64_t r = r0 + m.ro; r < r1; r += m.RP) {
-                T a[W], d[W];
+                T a[W], d[W], yo[W];
                 GbnVec<T>::unpack(px[(size_t)r * CV], a);
                 GbnVec<T>::unpack(pd[(size_t)r * CV], d);
+                if (MODE == 2) GbnVec<T>::unpack(py[(size_t)r * CV], yo);
                 for (int e = 0; e < W; ++e) {
                     if (RELU && !(fma(a[e], sc[e], sh[e]) > (T)0)) continue;
+                    if (MODE == 2 && !(yo[e] > (T)0)) continue;
                     const double dv = (double)d[e];
                     s[k][e] += dv;
                     q[k][e] = fma(dv, ((double)a[e] - (double)mu[e]) * (double)is[e], q[k][e]);
@@ -329,14 +341,16 @@ __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(double *__restric
     }
 }
 
-template <typename T, bool RELU>
+template <typename T, int MODE>
 __global__ __launch_bounds__(GBN_TPB) void gbn_bwd_apply_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                                const T *__restrict__ yout,
                                                                 const int32_t *__restrict__ group_of,
                                                                 const T *__restrict__ k1, const T *__restrict__ k2,
                                                                 const T *__restrict__ k3, const T *__restrict__ scale,
                                                                 const T *__restrict__ shift, T *__restrict__ dx,
-                                                                int64_t S, int C)
+                                                                T *__restrict__ dres, int64_t S, int C)
 {
+    constexpr bool RELU = MODE == 1;
     constexpr int W = GbnVec<T>::W;
     typedef typename GbnVec<T>::V V;
     extern __shared__ __attribute__((aligned(16))) unsigned char gbn_smem[];
@@ -356,12 +370,21 @@ __global__ __launch_bounds__(GBN_TPB) void gbn_bwd_apply_kernel(const T *__restr
     const size_t off = (size_t)n * S * C;
     const V *xp = reinterpret_cast<const V *>(x + off);
     const V *dp = reinterpret_cast<const V *>(dy + off);
+    const V *yp = MODE == 2 ? reinterpret_cast<const V *>(yout + off) : nullptr;
     V *op = reinterpret_cast<V *>(dx + off);
+    V *rp = MODE == 2 ? reinterpret_cast<V *>(dres + off) : nullptr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const int col = (int)(i % CV);
         T a[W], d[W], c1[W], c2[W], c3[W], o[W];
         GbnVec<T>::unpack(xp[i], a);
         GbnVec<T>::unpack(dp[i], d);
+        if (MODE == 2) {                    // the gradient that passes the block's ReLU: also the residual branch's gradient
+            T yo[W];
+            GbnVec<T>::unpack(yp[i], yo);
+            for (int e = 0; e < W; ++e)
+                if (!(yo[e] > (T)0)) d[e] = (T)0;
+            rp[i] = GbnVec<T>::pack(d);
+        }
         GbnVec<T>::unpack(*reinterpret_cast<const V *>(tab + col * W), c1);
         GbnVec<T>::unpack(*reinterpret_cast<const V *>(tab + C + col * W), c2);
         GbnVec<T>::unpack(*reinterpret_cast<const V *>(tab + 2 * C + col * W), c3);
@@ -414,9 +437,12 @@ extern "C" int64_t sp3d_gbn_workspace_bytes(int G, int C)
 
 extern "C" int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t *group_of, const int32_t *group_samples,
                                 int N, int64_t S, int C, int G, int G_update, const void *weight, const void *bias,
-                                void *running_mean, void *running_var, double eps, double momentum, int relu, void *mean,
-                                void *invstd, void *scale, void *shift, double *workspace, void *stream)
+                                void *running_mean, void *running_var, double eps, double momentum, int mode,
+                                const void *residual, void *mean, void *invstd, void *scale, void *shift, double *workspace,
+                                void *stream)
 {
+    if (mode < 0 || mode > 2) return SP3D_EINVAL;
+    if (mode == 2 && !residual) return SP3D_ENULL;
     const int R = SP3D_GBN_REPLICAS;
     int rc = gbn_check(dtype, N, S, C, G, R);
     if (rc) return rc;
@@ -439,8 +465,9 @@ extern "C" int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t
         hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, G_update,
                            (const T *)weight, (const T *)bias, (T *)running_mean, (T *)running_var, eps, momentum, (T *)mean,
                            (T *)invstd, (T *)scale, (T *)shift);
-        if (relu) hipLaunchKernelGGL((gbn_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
-        else hipLaunchKernelGGL((gbn_apply_kernel<T, false>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
+        if (mode == 2) hipLaunchKernelGGL((gbn_apply_kernel<T, 2>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)residual, (T *)y, S, C);
+        else if (mode == 1) hipLaunchKernelGGL((gbn_apply_kernel<T, 1>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)nullptr, (T *)y, S, C);
+        else hipLaunchKernelGGL((gbn_apply_kernel<T, 0>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)nullptr, (T *)y, S, C);
     } else {
         typedef double T;
         const size_t lds = 2 * (size_t)C * sizeof(T);
@@ -448,17 +475,22 @@ extern "C" int sp3d_gbn_forward(const void *x, void *y, int dtype, const int32_t
         hipLaunchKernelGGL(gbn_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, G_update,
                            (const T *)weight, (const T *)bias, (T *)running_mean, (T *)running_var, eps, momentum, (T *)mean,
                            (T *)invstd, (T *)scale, (T *)shift);
-        if (relu) hipLaunchKernelGGL((gbn_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
-        else hipLaunchKernelGGL((gbn_apply_kernel<T, false>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (T *)y, S, C);
+        if (mode == 2) hipLaunchKernelGGL((gbn_apply_kernel<T, 2>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)residual, (T *)y, S, C);
+        else if (mode == 1) hipLaunchKernelGGL((gbn_apply_kernel<T, 1>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)nullptr, (T *)y, S, C);
+        else hipLaunchKernelGGL((gbn_apply_kernel<T, 0>), ga, dim3(GBN_TPB), lds, s, (const T *)x, group_of, (const T *)scale, (const T *)shift, (const T *)nullptr, (T *)y, S, C);
     }
     return gbn_status();
 }
 
 extern "C" int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dtype, const int32_t *group_of,
                                  const int32_t *group_samples, int N, int64_t S, int C, int G, const void *weight,
-                                 const void *mean, const void *invstd, const void *scale, const void *shift, int relu,
-                                 void *grad_weight, void *grad_bias, void *k123, double *workspace, void *stream)
+                                 const void *mean, const void *invstd, const void *scale, const void *shift, int mode,
+                                 const void *y, void *grad_residual, void *grad_weight, void *grad_bias, void *k123,
+                                 double *workspace, void *stream)
 {
+    if (mode < 0 || mode > 2) return SP3D_EINVAL;
+    if (mode == 2 && (!y || !grad_residual)) return SP3D_ENULL;
+    const int relu = mode == 1;
     const int R = SP3D_GBN_REPLICAS;
     int rc = gbn_check(dtype, N, S, C, G, R);
     if (rc) return rc;
@@ -480,11 +512,13 @@ extern "C" int sp3d_gbn_backward(const void *x, const void *dy, void *dx, int dt
         typedef T_ T;                                                                                                             \
         T *k1 = (T *)k123, *k2 = k1 + gc, *k3 = k2 + gc;                                                                          \
         const size_t lds = 5 * (size_t)C * sizeof(T);                                                                             \
-        if (relu) hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, true>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
-        else hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, false>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
+        if (mode == 2) hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, 2>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, (const T *)y, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
+        else if (relu) hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, 1>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, (const T *)nullptr, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
+        else hipLaunchKernelGGL((gbn_bwd_stats_kernel<T, 0>), gs, dim3(GBN_TPB), 0, s, (const T *)x, (const T *)dy, (const T *)nullptr, group_of, (const T *)mean, (const T *)invstd, (const T *)scale, (const T *)shift, S, C, G, R, rows, workspace); \
         hipLaunchKernelGGL(gbn_bwd_finalize_kernel<T>, gf, dim3(256), 0, s, workspace, group_samples, S, C, G, (const T *)weight, (const T *)mean, (const T *)invstd, k1, k2, k3, (T *)grad_weight, (T *)grad_bias); \
-        if (relu) hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, true>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, S, C); \
-        else hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, false>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, S, C); \
+        if (mode == 2) hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, 2>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, (const T *)y, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, (T *)grad_residual, S, C); \
+        else if (relu) hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, 1>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, (const T *)nullptr, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, (T *)nullptr, S, C); \
+        else hipLaunchKernelGGL((gbn_bwd_apply_kernel<T, 0>), ga, dim3(GBN_TPB), lds, s, (const T *)x, (const T *)dy, (const T *)nullptr, group_of, k1, k2, k3, (const T *)scale, (const T *)shift, (T *)dx, (T *)nullptr, S, C); \
     }
     if (dtype == SP3D_GBN_F32) SP3D_GBN_BWD(float)
     else SP3D_GBN_BWD(double)

@@ -91,7 +91,8 @@ _DT = {torch.float32: 0, torch.float64: 1}
 
 class _GroupedBNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, spec: GroupSpec, eps: float, momentum: float, relu: bool):
+    def forward(ctx, x, weight, bias, running_mean, running_var, spec: GroupSpec, eps: float, momentum: float, relu: bool,
+                residual=None):
         lib = _lib.load()
         _lib._require_cuda(x, "x")
         if x.dtype not in _DT:
@@ -99,6 +100,11 @@ class _GroupedBNFn(torch.autograd.Function):
         x, N, S, C_ = _as_rows(x)
         if N != spec.N:
             raise _lib.Sp3dError(f"grouped BatchNorm: batch of {N} samples, GroupSpec describes {spec.N}")
+        mode = 2 if residual is not None else (1 if relu else 0)
+        if residual is not None:
+            if not relu or residual.shape != x.shape or residual.dtype != x.dtype:
+                raise _lib.Sp3dError("grouped BatchNorm: a residual (same shape and dtype as x) goes with relu=True")
+            residual = _as_rows(residual.detach())[0]
         dev = x.device
         y = torch.empty_like(x)                                   # keeps the channels-last strides
         stats = torch.empty((4, spec.G, C_), dtype=x.dtype, device=dev)      # mean, invstd, scale, shift
@@ -112,33 +118,39 @@ class _GroupedBNFn(torch.autograd.Function):
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         rc = lib.sp3d_gbn_forward(p(x), p(y), _DT[x.dtype], p(spec.group_of), p(spec.group_samples), N, C.c_int64(S), C_,
                                   spec.G, spec.n_update, p(w), p(b), p(rm), p(rv), C.c_double(eps), C.c_double(momentum),
-                                  int(relu), p(stats[0]), p(stats[1]), p(stats[2]), p(stats[3]), p(ws),
+                                  mode, p(residual), p(stats[0]), p(stats[1]), p(stats[2]), p(stats[3]), p(ws),
                                   C.c_void_p(_lib._stream(dev)))
         _lib.check(rc, "sp3d_gbn_forward")
-        ctx.save_for_backward(x, w, stats)
-        ctx.spec, ctx.relu, ctx.geom = spec, bool(relu), (N, S, C_)
+        if mode == 2:
+            ctx.save_for_backward(x, w, stats, y)                 # the block's output is what the next layer keeps anyway
+        else:
+            ctx.save_for_backward(x, w, stats)
+        ctx.spec, ctx.mode, ctx.geom = spec, mode, (N, S, C_)
         ctx.has_affine = (weight is not None, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, stats = ctx.saved_tensors
+        x, w, stats = ctx.saved_tensors[:3]
+        yout = ctx.saved_tensors[3] if ctx.mode == 2 else None
         spec, (N, S, C_) = ctx.spec, ctx.geom
         fmt = torch.channels_last if x.dim() == 4 else torch.channels_last_3d
         dy = dy.contiguous(memory_format=fmt)
         dev = x.device
         dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.mode == 2 else None
         gw = torch.empty(C_, dtype=x.dtype, device=dev)
         gb = torch.empty(C_, dtype=x.dtype, device=dev)
         k123 = torch.empty((3, spec.G, C_), dtype=x.dtype, device=dev)
         ws = spec.workspace(C_, dev)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         rc = lib.sp3d_gbn_backward(p(x), p(dy), p(dx), _DT[x.dtype], p(spec.group_of), p(spec.group_samples), N, C.c_int64(S),
-                                   C_, spec.G, p(w), p(stats[0]), p(stats[1]), p(stats[2]), p(stats[3]), int(ctx.relu), p(gw),
-                                   p(gb), p(k123), p(ws), C.c_void_p(_lib._stream(dev)))
+                                   C_, spec.G, p(w), p(stats[0]), p(stats[1]), p(stats[2]), p(stats[3]), ctx.mode, p(yout),
+                                   p(dres), p(gw), p(gb), p(k123), p(ws), C.c_void_p(_lib._stream(dev)))
         _lib.check(rc, "sp3d_gbn_backward")
-        return dx, (gw if ctx.has_affine[0] else None), (gb if ctx.has_affine[1] else None), None, None, None, None, None, None
+        return (dx, (gw if ctx.has_affine[0] else None), (gb if ctx.has_affine[1] else None), None, None, None, None, None, None,
+                dres)
 
 
 def _declare(lib):
@@ -148,9 +160,9 @@ def _declare(lib):
     lib.sp3d_gbn_workspace_bytes.restype = L
     lib.sp3d_gbn_workspace_bytes.argtypes = [I, I]
     lib.sp3d_gbn_forward.restype = I
-    lib.sp3d_gbn_forward.argtypes = [P, P, I, P, P, I, L, I, I, I, P, P, P, P, D, D, I, P, P, P, P, P, P]
+    lib.sp3d_gbn_forward.argtypes = [P, P, I, P, P, I, L, I, I, I, P, P, P, P, D, D, I, P, P, P, P, P, P, P]
     lib.sp3d_gbn_backward.restype = I
-    lib.sp3d_gbn_backward.argtypes = [P, P, P, I, P, P, I, L, I, I, P, P, P, P, P, I, P, P, P, P, P]
+    lib.sp3d_gbn_backward.argtypes = [P, P, P, I, P, P, I, L, I, I, P, P, P, P, P, I, P, P, P, P, P, P, P]
     lib._gbn_declared = True
 
 
@@ -158,16 +170,19 @@ class _GroupedMixin:
     """train mode + an attached GroupSpec: the grouped kernels; otherwise the parent BatchNorm"""
     groups: Optional[GroupSpec] = None
 
-    def grouped_forward(self, x, relu: bool = False):
+    def grouped_forward(self, x, relu: bool = False, residual=None):
+        """BatchNorm [+ residual] [+ ReLU]; with a spec attached in train mode ONE pass of the grouped kernels"""
         spec = self.groups
         if spec is None or not self.training:
             y = super().forward(x)
+            if residual is not None:
+                y = y + residual
             return torch.relu_(y) if relu else y
         if self.momentum is None or not self.track_running_stats:
             raise ValueError("grouped BatchNorm needs a numeric momentum and running statistics (as the reference's layers)")
         _declare(_lib.load())
         y = _GroupedBNFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, spec, float(self.eps),
-                               float(self.momentum), bool(relu))
+                               float(self.momentum), bool(relu), residual)
         with torch.no_grad():
             self.num_batches_tracked += spec.n_update
         return y

@@ -76,6 +76,13 @@ def _bn2(c):
     return ViewBatchNorm2d(c, momentum=_BN_MOM)
 
 
+def _bn_add_relu(bn, relu, y, identity):
+    """relu(bn(y) + identity), the tail of a residual block; with a GroupSpec attached in train mode ONE pass"""
+    if getattr(bn, "groups", None) is not None and bn.training:
+        return bn.grouped_forward(y, relu=True, residual=identity)
+    return relu(bn(y) + identity)
+
+
 def _bn_relu(bn, relu, x):
     """relu(bn(x)); with a GroupSpec attached in train mode BatchNorm and ReLU are ONE pass (the ReLU's mask is recomputed
     from the input in the backward, grouped_bn.py)"""
@@ -97,8 +104,8 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.bn2(self.conv2(_bn_relu(self.bn1, self.relu, self.conv1(x))))
-        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+        y = self.conv2(_bn_relu(self.bn1, self.relu, self.conv1(x)))
+        return _bn_add_relu(self.bn2, self.relu, y, x if self.downsample is None else self.downsample(x))
 
 
 class Bottleneck(nn.Module):
@@ -118,8 +125,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = _bn_relu(self.bn1, self.relu, self.conv1(x))
         y = _bn_relu(self.bn2, self.relu, self.conv2(y))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+        return _bn_add_relu(self.bn3, self.relu, self.conv3(y), x if self.downsample is None else self.downsample(x))
 
 
 _SPEC = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),

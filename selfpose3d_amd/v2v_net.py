@@ -151,9 +151,9 @@ class Residual3d(nn.Module):
 
     def forward(self, x):
         rb = self.res_branch
-        if _grouped(rb[1], self.training):
-            y = rb[4](rb[3](rb[1].grouped_forward(rb[0](x), relu=True)))
-            return F.relu(y + self.skip_con(x), True)
+        if _grouped(rb[1], self.training):          # BatchNorm + ReLU, and the block's tail BatchNorm + add + ReLU, one pass each
+            h = rb[3](rb[1].grouped_forward(rb[0](x), relu=True))
+            return rb[4].grouped_forward(h, relu=True, residual=self.skip_con(x))
         return F.relu(self.res_branch(x) + self.skip_con(x), True)
 
 

@@ -301,3 +301,49 @@ def test_soft_argmax_training_pair_matches_the_torch_graph(dev):
         assert float((out.double() - ref).abs().max()) <= 2e-3                # mm, on a 2 m cube
         assert _rel(x.grad, xd.grad) <= 2e-4
         assert x.grad.shape == x.shape
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dims,spatial,C,group_of", [(3, (8, 6, 5), 32, [0, 0, 1, 1, 2]), (2, (10, 12), 256, [0, 1, 2, 0, 1, 2])])
+def test_residual_block_tail_in_one_pass(dev, dims, spatial, C, group_of, dtype):
+    """mode SP3D_GBN_ADD_RELU: y = relu(BatchNorm(x) + residual) - the tail of Res3DBlock (lib/models/v2v_net.py:42-45) and
+    of the ResNet blocks - against per-group nn.BatchNorm + add + relu in float64: output, gradients of x, of the residual
+    (the masked upstream gradient), of weight and bias, running statistics"""
+    from selfpose3d_amd.grouped_bn import GroupedBatchNorm2d, GroupedBatchNorm3d, GroupSpec
+    G = max(group_of) + 1
+    sizes = [group_of.count(g) for g in range(G)]
+    gen = torch.Generator().manual_seed(77)
+    N = len(group_of)
+    fmt = torch.channels_last_3d if dims == 3 else torch.channels_last
+    x = (torch.randn((N, C) + spatial, generator=gen) * 2 + 1).to(dev)
+    r = torch.randn((N, C) + spatial, generator=gen).to(dev)
+    w, b = (torch.rand(C, generator=gen) + 0.5).to(dev), torch.randn(C, generator=gen).to(dev)
+    gy = torch.randn((N, C) + spatial, generator=gen).to(dev)
+    ref_bn = (nn.BatchNorm3d if dims == 3 else nn.BatchNorm2d)(C).to(dev).double().train()
+    with torch.no_grad():
+        ref_bn.weight.copy_(w); ref_bn.bias.copy_(b)
+    xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    go = torch.as_tensor(group_of, device=dev)
+    yref = torch.zeros_like(xd)
+    for g in range(G):
+        idx = torch.nonzero(go == g).flatten()
+        yref = yref.index_put((idx,), torch.relu(ref_bn(xd[idx]) + rd[idx]))
+    (yref * gy.double()).sum().backward()
+    bn = (GroupedBatchNorm3d if dims == 3 else GroupedBatchNorm2d)(C).to(dev).to(dtype).train()
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b)
+    bn.groups = GroupSpec(sizes, dev, group_of=group_of)
+    xi = x.to(dtype).contiguous(memory_format=fmt).requires_grad_(True)
+    ri = r.to(dtype).contiguous(memory_format=fmt).requires_grad_(True)
+    y = bn.grouped_forward(xi, relu=True, residual=ri)
+    (y * gy.to(dtype)).sum().backward()
+    ty, tg, ts = (1e-9, 1e-7, 1e-12) if dtype == torch.float64 else (1e-5, 5e-5, 1e-5)
+    assert _rel(y, yref) <= ty
+    assert _rel(xi.grad, xd.grad) <= tg and _rel(ri.grad, rd.grad) <= tg
+    assert _rel(bn.weight.grad, ref_bn.weight.grad) <= tg and _rel(bn.bias.grad, ref_bn.bias.grad) <= tg
+    assert _rel(bn.running_mean, ref_bn.running_mean) <= ts and _rel(bn.running_var, ref_bn.running_var) <= ts
+    # without a spec / in eval mode the same call is the plain modules
+    bn.groups = None
+    plain = bn.grouped_forward(xi.detach(), relu=True, residual=ri.detach())
+    want = torch.relu(nn.functional.batch_norm(xi.detach(), None, None, bn.weight, bn.bias, True, 0.0, bn.eps) + ri.detach())
+    assert _rel(plain, want) <= 1e-5
