@@ -87,6 +87,7 @@ def _as_rows(x: torch.Tensor):
 
 
 _DT = {torch.float32: 0, torch.float64: 1}
+FUSE_TAIL = __import__("os").environ.get("SP3D_GBN_FUSE_TAIL", "1") != "0"
 
 
 class _GroupedBNFn(torch.autograd.Function):
@@ -173,6 +174,8 @@ class _GroupedMixin:
     def grouped_forward(self, x, relu: bool = False, residual=None):
         """BatchNorm [+ residual] [+ ReLU]; with a spec attached in train mode ONE pass of the grouped kernels"""
         spec = self.groups
+        if residual is not None and not FUSE_TAIL and spec is not None and self.training:      # A/B switch (measurement)
+            return torch.relu_(self.grouped_forward(x, False) + residual)
         if spec is None or not self.training:
             y = super().forward(x)
             if residual is not None:

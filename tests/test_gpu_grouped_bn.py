@@ -206,6 +206,7 @@ def test_v2vnet_all_slots_in_one_call_equals_the_per_slot_loop_float64(dev):
     assert all(m.groups is None for m in one_net.modules() if isinstance(m, GroupedBatchNorm3d))     # the spec is detached again
 
 
+@pytest.mark.miopen_sensitive            # fp32 through the library's convolutions at two batch compositions: collected last
 @pytest.mark.parametrize("ssv_sets", [1, 2])
 def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
     """PoseRegressionNet.forward_slots (one indexed unprojection per view set, one V2V pass, grouped BatchNorm) against the
@@ -246,7 +247,7 @@ def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
     preds_o = net_o.forward_slots(sets_o, gc)
     sum((p * wgt[s]).sum() for s, p in enumerate(preds_o)).backward()
     for s in range(ssv_sets):
-        d = float((preds_o[s] - preds_l[s]).abs().max())
+        d = float((preds_o[s] - preds_l[s]).detach().abs().max())
         # mm, on 2000 mm cubes: the library's fp32 convolution kernels differ by batch size, and the soft-argmax of a
         # random-weight net amplifies their rounding (the float64 test above is the exact proof; a pooled or misassigned
         # statistic moves joints by centimetres)
