@@ -99,10 +99,12 @@ class PoseRegressionNet(nn.Module):
         pred[bi, ki] = torch.cat(outs, 0)
         return pred
 
-    # cube counts the slot-batched training call may be padded to (zero cubes in a BatchNorm group of their own, dropped
-    # afterwards): None = never pad, every distinct count is its own set of MIOpen convolution shapes (one kernel search
-    # each, kept in the user find-db); a tuple = round up to the next listed size, so the library only ever sees those
-    slot_pad_sizes = None
+    # cube counts the slot-batched training call is padded to (zero cubes in a BatchNorm group of their own, dropped
+    # afterwards).  The number of valid cubes changes from step to step with the people in the frames (1 .. B x K), and every
+    # distinct count is its own set of MIOpen convolution shapes = one kernel search each.  "auto" (default): round up to a
+    # multiple of ceil(B K / 4), so the library only ever sees FOUR batch sizes (B = 2, K = 10: 5, 10, 15, 20); a tuple:
+    # round up to the next listed size; None: never pad (every count searched once, kept in the user find-db)
+    slot_pad_sizes = "auto"
 
     def can_batch_slots(self) -> bool:
         """all normalisation layers still are grouped BatchNorm (a SyncBatchNorm conversion, say, replaces them: then the
@@ -156,8 +158,12 @@ class PoseRegressionNet(nn.Module):
             grids.append(g)
         x = cubes[0] if ns == 1 else torch.cat(cubes, 0)
         total, n_update = ns * P, len(sizes)
-        if self.slot_pad_sizes:
-            target = next((s for s in sorted(self.slot_pad_sizes) if s >= total), total)
+        pad = self.slot_pad_sizes
+        if pad == "auto":
+            q = -(-(B * K * ns) // 4)
+            pad = (q, 2 * q, 3 * q, 4 * q)
+        if pad:
+            target = next((s for s in sorted(pad) if s >= total), total)
             if target > total:                                     # zero cubes, a group of their own, no running update
                 x = torch.cat([x, x.new_zeros((target - total,) + tuple(x.shape[1:]))], 0)
                 group_of += [len(sizes)] * (target - total)

@@ -263,7 +263,9 @@ def test_pose_net_forward_slots_equals_the_loop_fp32(dev, ssv_sets):
     assert worst <= 5e-2, (worst, where)
     # padding to a listed cube count: zero cubes in their own group change nothing
     net_p, net_q = make(), make()
+    assert net_p.slot_pad_sizes == "auto"                    # default: multiples of ceil(B K / 4) -> four batch sizes at most
     net_p.slot_pad_sizes = (8, 16)
+    net_q.slot_pad_sizes = None
     with torch.no_grad():
         pp = net_p.forward_slots([(sets_o[0][0], sets_o[0][1], sets_o[0][2])], gc)[0]
         pq = net_q.forward_slots([(sets_o[0][0], sets_o[0][1], sets_o[0][2])], gc)[0]
