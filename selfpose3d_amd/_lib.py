@@ -42,11 +42,24 @@ class Sp3dError(RuntimeError):
 
 
 def shared_gpu() -> bool:
-    """SP3D_SHARED_GPU=1: this process is not alone on its GPU (another process, or a second stream of its own, may run
+    """SP3D_SHARED_GPU=1 (or, when the variable is unset, more local ranks than GPUs): this process is not alone on its GPU (another process, or a second stream of its own, may run
     kernels at the same time).  The library flavour without packed-fp32 instructions is loaded then (libsp3d_nopk.so):
     v_pk_*_f32 results come out wrong while wino_fused16_kernel's matrix instructions run on the same CU
     (profiles/r04_gpu_sharing_finding.md; tests/test_gpu_shared_gpu.py holds the two-stream regression)."""
-    return os.environ.get("SP3D_SHARED_GPU", "0").lower() in ("1", "true", "yes", "on")
+    v = os.environ.get("SP3D_SHARED_GPU")
+    if v is not None:
+        return v.lower() in ("1", "true", "yes", "on")
+    # not told: a launcher that starts more local ranks than there are GPUs (torchrun's LOCAL_WORLD_SIZE) makes ranks share
+    try:
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        if ranks > 1 and torch.cuda.is_available() and ranks > torch.cuda.device_count():
+            import warnings
+            warnings.warn(f"selfpose3d_amd: {ranks} local ranks on {torch.cuda.device_count()} GPU(s) - ranks share a GPU: loading "
+                          "libsp3d_nopk.so (no packed-fp32 instructions; set SP3D_SHARED_GPU=0 to force the default flavour)")
+            return True
+    except ValueError:
+        pass
+    return False
 
 
 def load():

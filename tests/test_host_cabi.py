@@ -452,3 +452,32 @@ def test_forward_views_keeps_the_per_view_loop_where_the_batched_pass_cannot_run
     # state_dict keys are BatchNorm2d's
     keys = [k for k in net.state_dict() if k.startswith("bn1.")]
     assert keys == ["bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked"]
+
+
+def test_shared_gpu_flavour_selection(monkeypatch):
+    """SP3D_SHARED_GPU picks the library flavour; unset, more local ranks than GPUs (torchrun's LOCAL_WORLD_SIZE) means sharing"""
+    monkeypatch.delenv("SP3D_SHARED_GPU", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert _lib.shared_gpu() is False
+    monkeypatch.setenv("SP3D_SHARED_GPU", "1")
+    assert _lib.shared_gpu() is True
+    monkeypatch.setenv("SP3D_SHARED_GPU", "0")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _lib.shared_gpu() is False                         # an explicit 0 wins
+    monkeypatch.delenv("SP3D_SHARED_GPU")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.warns(UserWarning, match="share a GPU"):
+        assert _lib.shared_gpu() is True                      # 8 local ranks, 1 GPU
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert _lib.shared_gpu() is False
+    assert os.path.basename(_lib.NOPK_LIB_PATH) == "libsp3d_nopk.so" and os.path.exists(_lib.NOPK_LIB_PATH)
+
+
+def test_nopk_flavour_exports_the_same_abi(lib):
+    """libsp3d_nopk.so (shared GPUs) is the same C ABI: every symbol of include/sp3d.h, same ABI version"""
+    nopk = C.CDLL(_lib.NOPK_LIB_PATH)
+    for name in _lib.EXPORTS:
+        assert hasattr(nopk, name), name
+    nopk.sp3d_abi_version.restype = C.c_int
+    assert nopk.sp3d_abi_version() == lib.sp3d_abi_version()
