@@ -681,7 +681,8 @@ def train_step_leg(args, rank, world, dev):
             host = {"error": f"{type(e).__name__}: {e}"}
     V = len(inputs)
     persons = int(sum(int(n) for n in meta[0]["num_person"]))
-    pose_calls = int(max(int(n) for n in meta[0]["num_person"]))         # one pose-net call per candidate slot in use
+    slots_in_use = int(max(int(n) for n in meta[0]["num_person"]))       # the reference: one pose-net call per slot in use
+    pose_calls = 1 if type(model).batch_slots_in_training else slots_in_use  # round 5: all slots in one pass (grouped BatchNorm)
     nbytes = int(sum(p.numel() for p in params) * 4)
     return {"metric": "multi-view frames/sec, full train step (BASELINE configs[2]), proposals = ground-truth roots",
             "value": round(D.job_throughput(Bt, args.train_steps, el, world), 3), "unit": "frames/s", "n_gpus": world,
@@ -692,9 +693,78 @@ def train_step_leg(args, rank, world, dev):
                            if world > 1 else "none (single process)"),
             "host_contention": host,
             "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
-            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "person_cubes_per_step": persons,
+            "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "candidate_slots_in_use": slots_in_use, "person_cubes_per_step": persons,
+            "backbone_pass": "all views in one channels_last pass, per-view BatchNorm statistics (grouped kernels)",
             "loss_last": float(state["loss"].detach()), "data": "synthetic frames built once per rank, resident on the device",
             "config": "configs/panoptic_synthetic_960x512_cam5.yaml (ResNet-50, 80x80x20 root grid, 64^3 pose cubes)"}
+
+
+def train_step_ssv_leg(args, rank, world, dev):
+    """Opt-in leg (--legs ...,train_step_ssv): the SELF-SUPERVISED pose-net stage at full size - what SelfPose3d itself trains
+    (reference configs/panoptic_ssl/resnet50/cam5_posenet.yaml; lib/models/multi_person_posenet_ssv.py:197-501): three view
+    sets of 5 x 960x512 through the ResNet-50 backbone, two through the ResNet-18 attention net, frozen root net on set 3,
+    pose net on both augmented sets for every proposal, re-projection + rendering losses, Adam.  Batch 2 per GPU
+    (BASELINE configs[2]).  As in the supervised leg the randomly initialised root net cannot propose people, so the frame's
+    ground-truth roots stand in for its proposals (wrapper around root_net.forward, here in bench.py)."""
+    from torch.utils.data import default_collate
+    from selfpose3d_amd import distributed as D
+    from selfpose3d_amd.config import load_config
+    from selfpose3d_amd.models import get_multi_person_pose_net
+    from selfpose3d_amd.synthetic_dataset import SyntheticPanopticSSV
+    cfg = load_config(os.path.join(ROOT, "configs", "cam5_posenet.yaml"), TRAIN__BATCH_SIZE=2)
+    Bt = int(cfg.TRAIN.BATCH_SIZE)
+    torch.backends.cudnn.benchmark = args.train_find == "search"
+    torch.manual_seed(D.rank_seed(0, rank))
+    model = get_multi_person_pose_net(cfg, is_train=True).to(dev)
+    model.use_channels_last(True)
+    for p in model.root_net.parameters():                        # FREEZE_ROOTNET (tools/train_3d.py select_trainable)
+        p.requires_grad_(False)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
+    ds = SyntheticPanopticSSV(cfg, num_frames=Bt, seed=D.rank_seed(1, rank) % 100000, max_people=3)
+    batch = default_collate([ds[i] for i in range(Bt)])
+    (in1, t1, w1, d1, m1, _, in2, t2, w2, d2, m2, _, in3, t3, w3, d3, m3, _) = batch
+    cl = lambda v: [x.to(dev).contiguous(memory_format=torch.channels_last) for x in v]
+    in1, in2, in3 = cl(in1), cl(in2), cl(in3)
+    dv = lambda v: [x.to(dev) for x in v]
+    t1, t2, t3, w1, w2, w3 = dv(t1), dv(t2), dv(t3), dv(w1), dv(w2), dv(w3)
+    root_forward = model.root_net.forward
+
+    def root_forward_gt(all_heatmaps, m, *a, **k):
+        out = root_forward(all_heatmaps, m, *a, **k)
+        gc = torch.zeros_like(out[3])
+        gc[:, :, 3] = -1.0
+        roots, nper = m[0]["roots_3d"].float().to(gc.device), m[0]["num_person"]
+        for i in range(gc.shape[0]):
+            n = int(nper[i])
+            gc[i, :n, :3] = roots[i, :n]
+            gc[i, :n, 3] = torch.arange(n, device=gc.device, dtype=torch.float32)
+            gc[i, :n, 4] = 1.0
+        return out[0], out[1], out[2], gc
+    model.root_net.forward = root_forward_gt
+    ddp = D.wrap_ddp(model, dev, find_unused=D.needs_find_unused(cfg))
+    ddp.train()
+    model.root_net.eval()
+    state = {}
+
+    def step():
+        _, _, _, losses = ddp(views1=in1, meta1=m1, targets_2d1=t1, weights_2d1=w1, targets_3d1=d1[0],
+                              views2=in2, meta2=m2, targets_2d2=t2, weights_2d2=w2, targets_3d2=d2[0],
+                              views3=in3, meta3=m3, targets_2d3=t3, weights_2d3=w3, targets_3d3=d3[0], epoch=int(cfg.TRAIN.L1_EPOCH))
+        loss = sum(v.mean() for v in losses.values() if v.requires_grad)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        state["loss"], state["keys"] = loss, sorted(losses)
+    el, _ = D.timed_steps(step, args.train_steps, args.train_warmup, dev)
+    persons = int(sum(int(n) for n in m3[0]["num_person"]))
+    return {"metric": "multi-view frames/sec, full SELF-SUPERVISED train step (pose-net stage), proposals = ground-truth roots",
+            "value": round(D.job_throughput(Bt, args.train_steps, el, world), 3), "unit": "frames/s", "n_gpus": world,
+            "ms_per_step": round(1e3 * el / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
+            "batch_per_gpu": Bt, "views": len(in1), "view_sets": 3, "person_cubes_per_step": 2 * persons, "pose_net_calls_per_step": 1,
+            "loss_terms": state["keys"], "loss_last": float(state["loss"].detach()), "dtype": "f32",
+            "config": "configs/cam5_posenet.yaml (reference cam5_posenet.yaml hyper-parameters), TRAIN.BATCH_SIZE = 2",
+            "data": "synthetic three-set frames built once per rank, resident on the device"}
 
 
 def cpu_reference_record():
@@ -848,6 +918,12 @@ def main():
             extra["train_step"] = train_step_leg(args, rank, world, dev)
         except Exception as e:                          # the headline must not die with a leg (all ranks fail alike)
             extra["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if "train_step_ssv" in legs:                                  # opt-in
+        try:
+            extra["train_step_ssv"] = train_step_ssv_leg(args, rank, world, dev)
+        except Exception as e:
+            extra["train_step_ssv"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         B = args.batch
