@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip", "sp3d_fft.hip", "sp3d_gbn.hip"]
-HEADERS = ["sp3d_device.h", "sp3d_proj_pk.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
+HEADERS = [os.path.join("..", "pk_src1.py"), "sp3d_device.h", "sp3d_proj_pk.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
 LIB = os.path.join(HERE, "libsp3d.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
@@ -41,22 +41,52 @@ PER_SOURCE_FLAGS = {"sp3d_winograd.hip": ["-fno-slp-vectorize"],
                     "sp3d_fft.hip": ["-fno-slp-vectorize"], "sp3d_fftconv.hip": ["-fno-slp-vectorize"]}
 
 
-def _compile_objects(objdir: str, extra_flags=(), verbose: bool = False):
-    """one hipcc -c per source, in parallel; returns the object paths"""
-    os.makedirs(objdir, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"]
-    procs, objs = [], []
-    for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + cflags + list(extra_flags) + PER_SOURCE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+LLVM_BIN = os.environ.get("SP3D_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def _compile_one(src: str, objdir: str, cflags, verbose: bool) -> str:
+    """One source -> one host object with its gfx950 code object inside, in the steps `hipcc -c` runs internally, with ONE
+    step added between the device compile and the assembler: `pk_src1.fix_asm` (no packed-fp32 instruction may take its low
+    result from the high half of source 1 - see selfpose3d_amd/pk_src1.py for the measurement behind that rule)."""
+    from . import pk_src1
+    base = os.path.join(objdir, src.replace(".hip", ""))
+    path = os.path.join(CSRC, src)
+    cuid = "-cuid=" + src.replace(".", "_")                     # device and host halves must agree on it
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    return objs
+        subprocess.check_call(cmd)
+    run([HIPCC] + cflags + ["-Wno-unused-command-line-argument", "--cuda-device-only", "-S", cuid, path, "-o", base + ".raw.s"])
+    with open(base + ".raw.s") as fh:
+        text, n = pk_src1.fix_asm(fh.read())
+    if pk_src1.count_risky(text):
+        raise RuntimeError(f"{src}: packed-fp32 instructions reading the high half of source 1 survive the rewrite")
+    with open(base + ".s", "w") as fh:
+        fh.write(text)
+    os.remove(base + ".raw.s")
+    if verbose:
+        print(f"{src}: {n} packed-fp32 instructions rewritten (source 0 <-> source 1)")
+    run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", base + ".s", "-o", base + ".dev.o"])
+    run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", base + ".hsaco", base + ".dev.o"])
+    run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + base + ".hsaco",
+         "-output=" + base + ".hipfb"])
+    run([HIPCC] + cflags + ["-Wno-unused-command-line-argument", "--cuda-host-only", cuid, "-Xclang", "-fcuda-include-gpubinary", "-Xclang",
+                            base + ".hipfb", "-c", path, "-o", base + ".o"])
+    for ext in (".dev.o", ".hsaco", ".hipfb"):
+        os.remove(base + ext)
+    return base + ".o"
+
+
+def _compile_objects(objdir: str, extra_flags=(), verbose: bool = False):
+    """every source through `_compile_one`, in parallel; returns the object paths"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        futs = [pool.submit(_compile_one, src, objdir, cflags + list(extra_flags) + PER_SOURCE_FLAGS.get(src, []), verbose) for src in SOURCES]
+        return [f.result() for f in futs]
 
 
 def _link(objs, out: str, verbose: bool = False):

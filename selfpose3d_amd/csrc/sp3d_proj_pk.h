@@ -23,9 +23,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #else
 // -DSP3D_NO_PK (libsp3d_nopk.so, built with -fno-slp-vectorize): the same operations as one plain VALU instruction per
-// component - no v_pk_*_f32 anywhere in the library.  For a GPU that is SHARED (two streams, two processes): packed-fp32
-// results come out wrong while waves of wino_fused16_kernel execute v_mfma_f32_16x16x32_bf16 on the same CU
-// (profiles/r04_gpu_sharing_finding.md, tests/test_gpu_shared_gpu.py); plain VALU is immune.  Same bits, ~6-9 % slower.
+// component - no v_pk_*_f32 anywhere in the library: the conservative flavour for a GPU that is SHARED (two streams, two
+// processes).  Same bits, ~6-9 % slower.  Background: ONE packed form - low result <- high half of source 1, both
+// multiplicands in vector registers - is wrong in lanes 48-63 while waves of another kernel execute gfx950's double-rate
+// matrix instructions on the same CU (profiles/r05_mfma_pk_hazard.md).  The compiler, not this header, picks operand order
+// and op_sel bits of the instructions it forms from the arithmetic below, so the BUILD removes that form from the default
+// flavour (selfpose3d_amd/pk_src1.py exchanges source 0 and source 1 in the generated assembly).
 struct v2f {
     float x, y;
 };

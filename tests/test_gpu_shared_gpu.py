@@ -1,8 +1,9 @@
 """Round-4 finding turned into code (profiles/r04_gpu_sharing_finding.md): while waves of wino_fused16_kernel execute
 v_mfma_f32_16x16x32_bf16 on a CU, packed-fp32 VALU results (v_pk_fma / v_pk_mul / v_pk_add_f32) of OTHER waves on that CU
-come out wrong - two streams of one process suffice.  One plan per GPU on one stream (the product's deployment) never
-co-schedules them; for a GPU that IS shared the library has a second flavour without any packed-fp32 instruction,
-libsp3d_nopk.so, loaded when SP3D_SHARED_GPU=1.  tools/shared_gpu_check.py runs the aggressor on stream A and the victims on
+come out wrong - two streams of one process suffice.  Round 5 reduced it to one instruction form (tools/mfma_pk_hazard5.hip:
+low result <- high half of a vector-register source 1) and the build now rewrites that form away (selfpose3d_amd/pk_src1.py),
+so BOTH flavours must be clean here: the default one, and libsp3d_nopk.so (no packed-fp32 instruction at all, loaded when
+SP3D_SHARED_GPU=1).  tools/shared_gpu_check.py runs the aggressor on stream A and the victims on
 stream B and counts results that differ BITWISE from the single-stream ones."""
 import json
 import os
@@ -41,12 +42,40 @@ def test_shared_gpu_flavour_is_immune_on_two_streams():
         assert bad == 0 and worst == 0.0, (name, bad, worst)
 
 
-@pytest.mark.xfail(strict=False, reason="the default flavour keeps its hand-written packed-fp32 unprojection arithmetic "
-                                        "(6-9 % faster) and is wrong next to wino_fused16_kernel's matrix instructions on the "
-                                        "same CU - by design it needs the GPU to itself (one plan, one stream); not strict: "
-                                        "whether a given box / run shows the interaction is not ours to promise")
 def test_default_flavour_on_two_streams():
+    """the default flavour keeps its packed-fp32 unprojection arithmetic; since the build rewrites every packed instruction
+    that took its low result from the high half of source 1 (selfpose3d_amd/pk_src1.py - the one form the interaction
+    affects, tools/mfma_pk_hazard5.hip) it is bit-identical next to the aggressor too.  Before that rewrite: 8 of 8 wrong."""
     rec = _check(shared=False)
     assert rec["library"].endswith("libsp3d.so"), rec
+    assert len(rec["victims"]) == 4
     for name, (bad, worst) in rec["victims"].items():
-        assert bad == 0, (name, bad, worst)
+        assert bad == 0 and worst == 0.0, (name, bad, worst)
+
+
+# packed-instruction forms of tools/mfma_pk_hazard5.hip that libsp3d.so may contain after the rewrite (columns of its table):
+# no modifier, high result <- low half of source 1, any selection on source 0 / source 2, scalar-register sources
+ALLOWED_FORMS = (0, 3, 4, 5, 8, 9, 10, 11)
+AFFECTED_FORMS = (1, 2, 6, 7)              # low result <- high half of a VECTOR-register source 1
+
+
+def test_packed_forms_the_library_uses_are_clean_next_to_matrix_instructions(tmp_path):
+    """the stand-alone form of the finding, run where the GPU suite runs: next to every kind of matrix instruction the
+    forms the build allows give 0 wrong results out of 5e9; the affected forms are only RECORDED (a later firmware / driver
+    may make them clean) - gpurun_out/mfma_pk_hazard5.json"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    exe = str(tmp_path / "h5")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-w", os.path.join(ROOT, "tools", "mfma_pk_hazard5.hip"), "-o", exe], check=True,
+                   timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("JSON ")][-1][5:])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "mfma_pk_hazard5.json"), "w") as f:
+        json.dump({"wrong_results_per_form": rec, "allowed_forms": ALLOWED_FORMS, "affected_forms": AFFECTED_FORMS}, f, indent=1)
+    assert len(rec) == 11
+    for neighbour, counts in rec.items():
+        for q in ALLOWED_FORMS:
+            assert counts[q] == 0, (neighbour, q, counts)
+    assert all(c == 0 for c in rec["none"]) and all(c == 0 for c in rec["v_fma_f32 only"]), rec

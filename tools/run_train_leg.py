@@ -7,4 +7,5 @@ import bench
 a = argparse.Namespace(train_find="search", train_steps=int(os.environ.get("STEPS", 6)), train_warmup=int(os.environ.get("WARMUP", 3)), share_gpu=False, legs_list=[])
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
-print(json.dumps(bench.train_step_leg(a, 0, 1, dev)))
+leg = bench.train_step_ssv_leg if os.environ.get("LEG") == "ssv" else bench.train_step_leg       # LEG=ssv: the self-supervised step
+print(json.dumps(leg(a, 0, 1, dev)))

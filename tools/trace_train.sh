@@ -4,6 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${TAG}_train_trace
 timeout 1500 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_train_trace -o train -- \
     python $R/tools/run_train_leg.py > $O/${TAG}_train_trace_leg.json 2> $O/${TAG}_train_trace.err
-python $R/tools/trace_tail.py $O/${TAG}_train_trace --ms 410 --top 60 > $O/${TAG}_train_step_kernels.md
+python $R/tools/trace_tail.py $O/${TAG}_train_trace --ms ${MS:-410} --top 60 > $O/${TAG}_train_step_kernels.md
 rm -rf $O/${TAG}_train_trace
 cat $O/${TAG}_train_trace_leg.json; cat $O/${TAG}_train_step_kernels.md | cut -c1-200
