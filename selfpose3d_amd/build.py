@@ -34,10 +34,11 @@ def needs_build() -> bool:
 # v_pk_fma_f32 the vectoriser forms out of the operand transforms cost more than the scalar instructions they replace
 # (half-resolution fused Winograd kernel 83.4 -> 78.5 us); the unprojection kernels, on the other hand, want it.
 PER_SOURCE_FLAGS = {"sp3d_winograd.hip": ["-fno-slp-vectorize"],
-                    # round 4: compiler-formed v_pk_*_f32 in these kernels come out WRONG when waves of wino_fused16_kernel
-                    # (v_mfma_f32_16x16x32_bf16) are resident on the same CU - two plans on one GPU, streams or processes
-                    # (profiles/r04_gpu_sharing_finding.md); without the vectoriser they are immune, at the same speed
-                    # (bench step 1.563 vs 1.569 ms)
+                    # round 4: the packed instructions the vectoriser formed in these kernels (complex multiplies: swapped
+                    # halves of source 1) came out wrong next to another plan's matrix instructions; without the vectoriser
+                    # they are immune at the same speed (bench step 1.563 vs 1.569 ms).  Round 5 found the one affected
+                    # instruction form and `_compile_one` rewrites it in every source (pk_src1.py), so this flag is no longer
+                    # what protects them - it stays because it costs nothing.
                     "sp3d_fft.hip": ["-fno-slp-vectorize"], "sp3d_fftconv.hip": ["-fno-slp-vectorize"]}
 
 
