@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void aggressor(float *out, int iters, unsig
 }
 
 // victim forms: kind 0 fma 1 mul 2 add; sl / sh = which half (0 low, 1 high) of each source feeds the low / high result
-struct Form { int kind, sl[3], sh[3]; const char *text; int sg = -1; };      // sg: which source is a scalar-register pair
+struct Form { int kind, sl[3], sh[3]; const char *text; int sg = -1; int neg[3] = {0, 0, 0}; float k1 = 0.f; };
+// sg: which source is a scalar-register pair; neg: source negated (neg_lo and neg_hi both); k1 != 0: source 1 is that inline constant
 __host__ __device__ constexpr Form form(int q)
 {
     switch (q) {
@@ -69,7 +70,12 @@ __host__ __device__ constexpr Form form(int q)
     case 8: return {1, {0, 1, 0}, {0, 0, 0}, "v_pk_mul_f32 v, v, S op_sel:[0,1] op_sel_hi:[0,0]  (as the compiler wrote it)", 1};
     case 9: return {1, {1, 0, 0}, {0, 0, 0}, "v_pk_mul_f32 v, S, v op_sel:[1,0] op_sel_hi:[0,0]  (Q8 with sources exchanged)", 0};
     case 10: return {0, {0, 1, 0}, {1, 1, 1}, "v_pk_fma_f32 v, S, v, v op_sel:[0,1,0]             (as the compiler wrote it)", 0};
-    default: return {0, {1, 0, 0}, {1, 1, 1}, "v_pk_fma_f32 v, v, S, v op_sel:[1,0,0]             (Q10 with sources exchanged)", 1};
+    case 11: return {0, {1, 0, 0}, {1, 1, 1}, "v_pk_fma_f32 v, v, S, v op_sel:[1,0,0]             (Q10 with sources exchanged)", 1};
+    // the other forms libsp3d.so contains (llvm-objdump of the finished library): negated sources, inline constants
+    case 12: return {0, {0, 0, 0}, {1, 0, 1}, "v_pk_fma_f32 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]", -1, {1, 0, 0}};
+    case 13: return {2, {0, 0, 0}, {1, 1, 0}, "v_pk_add_f32 neg_lo:[0,1] neg_hi:[0,1]                 (a subtraction)", -1, {0, 1, 0}};
+    case 14: return {1, {0, 0, 0}, {1, 0, 0}, "v_pk_mul_f32 v, v, 0.5 op_sel_hi:[1,0]", -1, {0, 0, 0}, 0.5f};
+    default: return {2, {0, 0, 0}, {1, 0, 0}, "v_pk_add_f32 v, v, 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]", -1, {1, 0, 0}, 1.0f};
     }
 }
 template <int Q>
@@ -104,6 +110,12 @@ __device__ inline void burst(v2 (&g)[8], const v2 (&x)[8], const v2 (&m)[8], con
     if (Q == 9) B2S0("v_pk_mul_f32", "op_sel:[1,0] op_sel_hi:[0,0]");
     if (Q == 10) B3S0("v_pk_fma_f32", "op_sel:[0,1,0]");
     if (Q == 11) B3S1("v_pk_fma_f32", "op_sel:[1,0,0]");
+    if (Q == 12) B3("v_pk_fma_f32", "op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]");
+    if (Q == 13) B2("v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]");
+#define B2K(op, k, mod) asm volatile(op " %0, %8, " k " " mod "\n" op " %1, %9, " k " " mod "\n" op " %2, %10, " k " " mod "\n" op " %3, %11, " k " " mod "\n" \
+                                     op " %4, %12, " k " " mod "\n" op " %5, %13, " k " " mod "\n" op " %6, %14, " k " " mod "\n" op " %7, %15, " k " " mod "\n" : OPS : INS)
+    if (Q == 14) B2K("v_pk_mul_f32", "0.5", "op_sel_hi:[1,0]");
+    if (Q == 15) B2K("v_pk_add_f32", "1.0", "op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]");
 }
 
 // out: [0] wrong results, [1] records taken, [2..65] wrong results per lane, [66 ..] up to 4 records of 10 floats
@@ -123,8 +135,11 @@ __global__ __launch_bounds__(256) void victim(unsigned *out, int iters, float sk
         const v2 sk = {sk0, sk1};
         burst<Q>(g, x, m, c, sk);
         for (int k = 0; k < 8; ++k) {
-            const v2 s0 = F.sg == 0 ? sk : x[k], s1 = F.sg == 1 ? sk : (F.sg == 0 ? x[k] : m[k]);       // what the instruction had as source 0 / 1
-            const float a0 = F.sl[0] ? s0.y : s0.x, a1 = F.sh[0] ? s0.y : s0.x, b0 = F.sl[1] ? s1.y : s1.x, b1 = F.sh[1] ? s1.y : s1.x;
+            const v2 kk = {F.k1, F.k1};
+            const v2 s0 = F.sg == 0 ? sk : x[k], s1 = F.k1 != 0.f ? kk : F.sg == 1 ? sk : (F.sg == 0 ? x[k] : m[k]);   // what the instruction had as source 0 / 1
+            const unsigned n0 = F.neg[0] ? 0x80000000u : 0u, n1 = F.neg[1] ? 0x80000000u : 0u;
+            const float a0 = __uint_as_float(__float_as_uint(F.sl[0] ? s0.y : s0.x) ^ n0), a1 = __uint_as_float(__float_as_uint(F.sh[0] ? s0.y : s0.x) ^ n0);
+            const float b0 = __uint_as_float(__float_as_uint(F.sl[1] ? s1.y : s1.x) ^ n1), b1 = __uint_as_float(__float_as_uint(F.sh[1] ? s1.y : s1.x) ^ n1);
             const float c0 = F.sl[2] ? c[k].y : c[k].x, c1 = F.sh[2] ? c[k].y : c[k].x;
             float w0, w1;
             if (F.kind == 0) { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(w0) : "v"(a0), "v"(b0), "v"(c0));
@@ -179,7 +194,7 @@ template <int K>
 static void row()
 {
     printf("%-32s", KNAME[K]);
-    cell<K, 0>(); cell<K, 1>(); cell<K, 2>(); cell<K, 3>(); cell<K, 4>(); cell<K, 5>(); cell<K, 6>(); cell<K, 7>(); cell<K, 8>(); cell<K, 9>(); cell<K, 10>(); cell<K, 11>();
+    cell<K, 0>(); cell<K, 1>(); cell<K, 2>(); cell<K, 3>(); cell<K, 4>(); cell<K, 5>(); cell<K, 6>(); cell<K, 7>(); cell<K, 8>(); cell<K, 9>(); cell<K, 10>(); cell<K, 11>(); cell<K, 12>(); cell<K, 13>(); cell<K, 14>(); cell<K, 15>();
     printf("\n");
 }
 
@@ -187,14 +202,15 @@ int main()
 {
     hipMalloc(&g_out, 128 * 4); hipMalloc(&g_dummy, 4);
     printf("wrong packed results out of %.0f checked per cell (4 launches x 2048 x 256 threads x 300 bursts of 8)\n", 4.0 * 2048 * 256 * 300 * 8);
-    for (int q = 0; q < 12; ++q) printf("  Q%d = %s\n", q, form(q).text);
-    printf("%-32s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s\n", "neighbour on stream A", "Q0", "Q1", "Q2", "Q3", "Q4", "Q5", "Q6", "Q7", "Q8", "Q9", "Q10", "Q11");
+    for (int q = 0; q < 16; ++q) printf("  Q%d = %s\n", q, form(q).text);
+    printf("%-32s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s%10s\n", "neighbour on stream A", "Q0", "Q1", "Q2", "Q3", "Q4", "Q5", "Q6", "Q7", "Q8", "Q9", "Q10",
+           "Q11", "Q12", "Q13", "Q14", "Q15");
     row<0>(); row<10>(); row<1>(); row<2>(); row<3>(); row<4>(); row<5>(); row<6>(); row<7>(); row<8>(); row<9>();
     const int order[11] = {0, 10, 1, 2, 3, 4, 5, 6, 7, 8, 9};
     printf("JSON {");                                            // one line for tests/test_gpu_shared_gpu.py
     for (int r = 0; r < 11; ++r) {
         printf("%s\"%s\": [", r ? ", " : "", KNAME[order[r]]);
-        for (int q = 0; q < 12; ++q) printf("%s%u", q ? ", " : "", g_counts[12 * r + q]);
+        for (int q = 0; q < 16; ++q) printf("%s%u", q ? ", " : "", g_counts[16 * r + q]);
         printf("]");
     }
     printf("}\n");
