@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave library-GEMM selection to the rocBLAS/hipBLASLt heuristics (default: opt in to TunableOp "
                          "for the inference plan's GEMMs, V2VNet.tune_gemms(True); recorded in config.gemm_selection)")
+    ap.add_argument("--leg-deadline", type=float, default=600.0,
+                    help="world > 1 only: seconds the legs after the headline measurement may take before rank 0 prints the line "
+                         "it has and every rank exits with status 0 (a collective that never returns must not lose the headline); "
+                         "0 disables")
     ap.add_argument("--legs", default="auto",
                     help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, unprojection_grids, unprojection_backward, or 'auto' "
                          "(all four: train_step = BASELINE configs[2], at every N) or 'none'")
@@ -824,7 +828,9 @@ def main():
     import torch.distributed as dist
     from selfpose3d_amd import distributed as D
     if world > 1:
-        D.init("gloo" if args.share_gpu else "nccl", dev)            # backend "nccl" == RCCL on ROCm
+        # control plane (barriers, max over ranks) on gloo, data plane (DDP gradient buckets of the train leg) on RCCL
+        # (backend "nccl" == RCCL on ROCm); ranks that share one GPU cannot form an RCCL communicator: gloo for both
+        D.init_split("gloo" if args.share_gpu else "nccl")
 
     miopen_db = use_shipped_miopen_db()        # before the first convolution of the process (a private directory per rank)
     tun = getattr(torch.cuda, "tunable", None)
@@ -874,8 +880,83 @@ def main():
         el_r, _ = D.timed_steps(step, args.steps, 0, dev)
         spread.append(1e3 * el_r / args.steps)
 
+    # ---- the line's headline part exists BEFORE any leg runs: a leg that never returns cannot take it along -----------
+    result = None
+    if rank == 0:
+        B = args.batch
+        V, J = len(hms), hms[0].shape[1]
+        value = D.job_throughput(B, args.steps, elapsed, world)
+        handover = "planar (B,J,h,w) -> pack(HIP) -> " if args.planar_input else "channels-last views of the backbone's buffer -> "
+        result = {
+            "metric": "multi-view samples/sec (5-view Panoptic, 80x80x20 voxel)",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "panoptic_5view_cuboid_proposal_net_fwd_b4 (BASELINE configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
+                       "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
+                       "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
+                       "process_groups": ("none (single process)" if world == 1 else
+                                          "control plane (barriers of the timed regions, max over ranks) on gloo; data plane = DDP "
+                                          "gradient buckets of legs.train_step only, on " + ("gloo" if args.share_gpu else "RCCL")),
+                       "step": "heat-maps(HBM, " + handover + "unproject(HIP) -> V2V(fp32 in/out, fp32 accumulation: 7^3 opening conv " +
+                               ("in the frequency domain (HIP z-DFT + 88x88 plane transforms + contraction)"
+                                if args.front_conv == "fft" else "MIOpen direct") +
+                               (", 3^3 convs as HIP kernels on the bf16 matrix pipe with exact 3-piece operand splits (direct conv at "
+                                "full resolution, fused Winograd F(2,3) at half resolution), Winograd transforms + rocBLAS at quarter "
+                                "resolution" if not args.no_winograd else "") +
+                               ", other convs GEMM/MIOpen) -> NMS/top-k(HIP)",
+                       "conv_arithmetic": "fp32 tensors; 3^3 products = 6 exact bf16 x bf16 partial products per fp32 multiply "
+                                          "(hi/mid/lo pieces, dropped terms < 2^-24 relative), fp32 accumulation; tested bound: "
+                                          "max error vs a float64 convolution <= 1.5x that of the fp32-MFMA kernel on the same "
+                                          "inputs (tests/test_gpu_parity.py); measured 2.3e-6 (split Winograd) / 9.1e-6 (direct split) "
+                                          "vs 2.4e-6 (fp32 MFMA) / 9.3e-6 (MIOpen direct fp32) on outputs of magnitude 8",
+                       "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
+                       "gemm_selection": ("library heuristics" if args.no_gemm_tuning else
+                                          "PyTorch TunableOp for the plan's rocBLAS/hipBLASLt GEMMs, opted in by bench.py "
+                                          "(V2VNet.tune_gemms(True)); process-wide flags restored after every forward"),
+                       "miopen_user_db": ("private copy of selfpose3d_amd/miopen_db (find results of this file's convolution "
+                                          "shapes: shortens warm-ups, same kernels as a fresh search)" if miopen_db else
+                                          "the process's own (MIOPEN_USER_DB_PATH / default)"),
+                       "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
+                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
+            "views_x_frames_per_s": round(value * V, 3),
+            "value_window": (f"first of {len(spread)} windows of {args.steps} steps; by ms_per_step it ranks "
+                             f"{1 + sorted(spread).index(spread[0])} of {len(spread)} (1 = fastest): legs measured later in the run may read "
+                             f"faster than `value` by up to the box_spread"),
+            "box_spread": {"ms_per_step_min": round(min(spread), 4), "ms_per_step_max": round(max(spread), 4),
+                           "repeats": len(spread), "steps_each": args.steps,
+                           "what": "the timed K steps (= value) and further repeats of K steps on the same box, same rule"},
+        }
+        if args.share_gpu:
+            result["share_gpu_note"] = ("ranks that share a GPU run libsp3d_nopk.so (SP3D_SHARED_GPU=1: no packed-fp32 instructions), "
+                                        "which is immune to the matrix-instruction / packed-fp32 interaction of "
+                                        "profiles/r04_gpu_sharing_finding.md; the output check is ENFORCED (profiles/r05_shared_gpu.md)")
+            result["config"]["parallelism"] = (f"SMOKE: {world} ranks share cuda:0, process group gloo (no RCCL): exercises the "
+                                               f"multi-rank code path, not a scaling number")
+            from selfpose3d_amd import _lib as _l
+            result["config"]["library"] = os.path.basename(_l.LIB_PATH)
     # ---- extra legs that every rank takes part in (same timing rule); rank 0 adds them to the one JSON line -----------
     extra = {}
+    # world > 1: everything below may sit in a collective that never returns (the DDP leg is the first place a multi-GPU
+    # RCCL communicator of this repo meets hardware).  Every rank arms the same deadline; when it expires rank 0 prints the
+    # line it has (headline measured above + the legs finished so far + what happened) and all ranks leave with status 0.
+    import threading
+    line_lock, line_state = threading.Lock(), {"printed": False}
+
+    def print_line_once(note=None):
+        with line_lock:
+            if rank != 0 or line_state["printed"]:
+                return
+            if note is not None:
+                extra["deadline"] = note
+            result.setdefault("legs", extra)
+            print(json.dumps(result), flush=True)
+            line_state["printed"] = True
+    deadline = D.Deadline(args.leg_deadline if world > 1 else 0.0,
+                          lambda: print_line_once(f"legs not finished {args.leg_deadline:.0f} s after the headline measurement: "
+                                                  f"line printed by the deadline thread, every rank exits (--leg-deadline)"))
+    deadline.__enter__()
     if "host_contention" in legs and world == 1:
         # host-side readiness for 8 ranks per node, measured on this 1-GPU box: the headline step (one graph replay + the
         # camera-table pack per step) and, in the train leg, the ~3 500-launch train step, re-timed with this process
@@ -927,55 +1008,6 @@ def main():
 
     if rank == 0:
         B = args.batch
-        V, J = len(hms), hms[0].shape[1]
-        value = D.job_throughput(B, args.steps, elapsed, world)
-        handover = "planar (B,J,h,w) -> pack(HIP) -> " if args.planar_input else "channels-last views of the backbone's buffer -> "
-        result = {
-            "metric": "multi-view samples/sec (5-view Panoptic, 80x80x20 voxel)",
-            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "panoptic_5view_cuboid_proposal_net_fwd_b4 (BASELINE configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world, "views": V, "joints": J,
-                       "heatmap": [int(hms[0].shape[3]), int(hms[0].shape[2])], "image": list(cfg.NETWORK.IMAGE_SIZE),
-                       "voxels": list(model.cube_size), "parallelism": f"frames sharded over {world} rank(s), no collective",
-                       "step": "heat-maps(HBM, " + handover + "unproject(HIP) -> V2V(fp32 in/out, fp32 accumulation: 7^3 opening conv " +
-                               ("in the frequency domain (HIP z-DFT + 88x88 plane transforms + contraction)"
-                                if args.front_conv == "fft" else "MIOpen direct") +
-                               (", 3^3 convs as HIP kernels on the bf16 matrix pipe with exact 3-piece operand splits (direct conv at "
-                                "full resolution, fused Winograd F(2,3) at half resolution), Winograd transforms + rocBLAS at quarter "
-                                "resolution" if not args.no_winograd else "") +
-                               ", other convs GEMM/MIOpen) -> NMS/top-k(HIP)",
-                       "conv_arithmetic": "fp32 tensors; 3^3 products = 6 exact bf16 x bf16 partial products per fp32 multiply "
-                                          "(hi/mid/lo pieces, dropped terms < 2^-24 relative), fp32 accumulation; tested bound: "
-                                          "max error vs a float64 convolution <= 1.5x that of the fp32-MFMA kernel on the same "
-                                          "inputs (tests/test_gpu_parity.py); measured 2.3e-6 (split Winograd) / 9.1e-6 (direct split) "
-                                          "vs 2.4e-6 (fp32 MFMA) / 9.3e-6 (MIOpen direct fp32) on outputs of magnitude 8",
-                       "heatmap_handover": "planar" if args.planar_input else "nhwc16_views",
-                       "gemm_selection": ("library heuristics" if args.no_gemm_tuning else
-                                          "PyTorch TunableOp for the plan's rocBLAS/hipBLASLt GEMMs, opted in by bench.py "
-                                          "(V2VNet.tune_gemms(True)); process-wide flags restored after every forward"),
-                       "miopen_user_db": ("private copy of selfpose3d_amd/miopen_db (find results of this file's convolution "
-                                          "shapes: shortens warm-ups, same kernels as a fresh search)" if miopen_db else
-                                          "the process's own (MIOPEN_USER_DB_PATH / default)"),
-                       "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
-                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
-            "views_x_frames_per_s": round(value * V, 3),
-            "value_window": (f"first of {len(spread)} windows of {args.steps} steps; by ms_per_step it ranks "
-                             f"{1 + sorted(spread).index(spread[0])} of {len(spread)} (1 = fastest): legs measured later in the run may read "
-                             f"faster than `value` by up to the box_spread"),
-            "box_spread": {"ms_per_step_min": round(min(spread), 4), "ms_per_step_max": round(max(spread), 4),
-                           "repeats": len(spread), "steps_each": args.steps,
-                           "what": "the timed K steps (= value) and further repeats of K steps on the same box, same rule"},
-        }
-        if args.share_gpu:
-            result["share_gpu_note"] = ("ranks that share a GPU run libsp3d_nopk.so (SP3D_SHARED_GPU=1: no packed-fp32 instructions), "
-                                        "which is immune to the matrix-instruction / packed-fp32 interaction of "
-                                        "profiles/r04_gpu_sharing_finding.md; the output check is ENFORCED (profiles/r05_shared_gpu.md)")
-            result["config"]["parallelism"] = (f"SMOKE: {world} ranks share cuda:0, process group gloo (no RCCL): exercises the "
-                                               f"multi-rank code path, not a scaling number")
-            from selfpose3d_amd import _lib as _l
-            result["config"]["library"] = os.path.basename(_l.LIB_PATH)
         if golden is not None and not args.no_check:
             result["output_check"] = check_output(out, golden)
         if not args.no_fp32_leg and not args.no_winograd and world == 1:
@@ -1054,11 +1086,13 @@ def main():
             except Exception as e:
                 extra["unprojection_backward"] = {"error": f"{type(e).__name__}: {e}"}
         result["legs"] = extra
-        print(json.dumps(result), flush=True)
+        print_line_once()
         if "output_check" in result and not result["output_check"]["ok"]:
             raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")
     if world > 1:
         dist.barrier()
+    deadline.__exit__(None, None, None)
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -21,6 +21,9 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+_DATA_GROUP = None            # set by init_split: the RCCL group gradients travel on (None: the default group)
+
+
 def init(backend: str | None = None, device: torch.device | None = None):
     rank, world, _ = env_world()
     if world > 1 and not dist.is_initialized():
@@ -30,6 +33,37 @@ def init(backend: str | None = None, device: torch.device | None = None):
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return rank, world
+
+
+def init_split(data_backend: str = "nccl", single_rank: bool = False):
+    """bench.py's process groups: the CONTROL plane (barriers around timed regions, max / sum of a few host numbers) is the
+    default group on gloo - host memory, TCP on 127.0.0.1, nothing on the GPU's queues - and the DATA plane (DDP's gradient
+    buckets) is a second group on ``data_backend`` ("nccl" = RCCL over xGMI), created lazily by its first collective.  The
+    forward-only path has no data-path collective, so its number depends on RCCL in no way: a
+    communicator that cannot be built fails the train leg (an error entry in the line), not the job.  ``single_rank``
+    builds the two groups at world size 1 too (tests/test_gpu_rccl_single_rank.py: the layout on the real library).
+    Returns (rank, world)."""
+    global _DATA_GROUP
+    rank, world, _ = env_world()
+    if (world > 1 or single_rank) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo")
+        _DATA_GROUP = dist.new_group(backend=data_backend)
+    return rank, world
+
+
+def data_group():
+    """the group gradients are reduced on (None = the default group)"""
+    return _DATA_GROUP
+
+
+def _host_group() -> bool:
+    """is the default group a host-memory one (gloo)?  Then the few numbers the timing rule exchanges stay on the host."""
+    try:
+        return dist.get_backend() == "gloo"
+    except Exception:
+        return False
 
 
 def shard_frames(num_frames: int, rank: int, world: int) -> List[int]:
@@ -46,7 +80,7 @@ def max_over_ranks(value: float, device=None) -> float:
     """bench timing rule: the job takes as long as its slowest rank"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None and not _host_group() else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -79,7 +113,7 @@ def sum_over_ranks(*values: float, device=None):
     """all-reduce(SUM) of a few python numbers (evaluation counters: every rank must score the WHOLE set)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tuple(float(v) for v in values)
-    t = torch.tensor(values, dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor(values, dtype=torch.float64, device=device if device is not None and not _host_group() else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return tuple(float(v) for v in t.tolist())
 
@@ -220,6 +254,44 @@ def host_contention(step, steps: int, device=None, base_ms=None):
     return out
 
 
+class Deadline:
+    """Bound on a region that may contain a collective which never returns (a communicator whose peer died, a fabric
+    link that is down): if the region is not left within ``seconds``, ``on_expire()`` runs on a helper thread and the
+    process ends with ``exit_code`` - every rank arms the same deadline, so the job ends together and the launcher sees a
+    clean exit instead of a hang.  bench.py arms it around the legs that follow the headline measurement at world > 1:
+    rank 0's ``on_expire`` prints the line it already has.  ``seconds <= 0`` disables it."""
+
+    def __init__(self, seconds: float, on_expire=None, exit_code: int = 0, _exit=None):
+        self.seconds, self.on_expire, self.exit_code = float(seconds), on_expire, exit_code
+        self._exit = _exit if _exit is not None else os._exit
+        self._timer, self.expired = None, False
+
+    def _fire(self):
+        self.expired = True
+        import sys
+        try:
+            if self.on_expire is not None:
+                self.on_expire()
+        except Exception as e:                      # the process ends whatever the handler did
+            print(f"[deadline] handler failed: {type(e).__name__}: {e}", file=sys.stderr)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        self._exit(self.exit_code)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self._timer = threading.Timer(self.seconds, self._fire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
 def job_throughput(units_per_rank_per_step: int, steps: int, seconds: float, world: int) -> float:
     """whole-job units/s under weak scaling: every rank processes its own `units_per_rank_per_step`"""
     return world * units_per_rank_per_step * steps / seconds
@@ -258,5 +330,5 @@ def wrap_ddp(model: torch.nn.Module, device: torch.device | None = None, find_un
     if device is not None and device.type == "cuda":
         return torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], output_device=device.index,
                                                          find_unused_parameters=find_unused, bucket_cap_mb=32,
-                                                         gradient_as_bucket_view=True)
-    return torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=find_unused)
+                                                         gradient_as_bucket_view=True, process_group=_DATA_GROUP)
+    return torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=find_unused, process_group=_DATA_GROUP)

@@ -243,3 +243,66 @@ def test_ssv_attention_net_is_anchored_on_early_return_paths(flags):
         assert p.exitcode == 0, "SSV loop failed or hung under DDP(find_unused_parameters=False)"
     res = [q.get(timeout=10) for _ in range(world)]
     assert all(missing == [] for _, missing in res), res
+
+
+def _split_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from selfpose3d_amd import distributed as D
+    r, w = D.init_split("gloo")                    # bench.py's groups; on the GPU box the data group is RCCL
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    assert D.data_group() is not None and D.data_group() is not dist.group.WORLD
+    # control plane: the timing rule's numbers are host tensors whatever `device` says
+    assert D.max_over_ranks(1.0 + rank, torch.device("cpu")) == float(world)
+    assert D.sum_over_ranks(1 + rank, 10) == (3.0, 20.0)
+    secs, last = D.timed_steps(lambda: rank, steps=2, warmup=1)
+    assert secs >= 0.0 and last == rank
+    # data plane: DDP reduces its gradient buckets on the data group -> the mean of the two ranks' gradients
+    torch.manual_seed(0)
+    net = torch.nn.Linear(3, 2)
+    ddp = D.wrap_ddp(net, find_unused=False)
+    assert ddp.process_group is D.data_group()
+    x = torch.full((1, 3), float(rank + 1))
+    ddp(x).sum().backward()
+    q.put((rank, net.weight.grad.tolist()))        # plain lists: a tensor in the queue needs the sender alive
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_plane_on_gloo_data_plane_on_its_own_group():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    # d(sum(Wx + b))/dW = x on every row; mean over the ranks' x = 1 and 2 -> 1.5
+    for g in res.values():
+        assert torch.allclose(torch.tensor(g), torch.full((2, 3), 1.5))
+
+
+def test_deadline_fires_once_and_cancels_cleanly():
+    import time
+    from selfpose3d_amd import distributed as D
+    fired, exits = [], []
+    with D.Deadline(0.05, lambda: fired.append(1), exit_code=0, _exit=exits.append) as d:
+        time.sleep(0.3)                            # the region overstays: handler, then the exit hook with the status
+    assert fired == [1] and exits == [0] and d.expired
+    fired2, exits2 = [], []
+    with D.Deadline(5.0, lambda: fired2.append(1), _exit=exits2.append) as d2:
+        pass                                       # left in time: the timer is cancelled
+    time.sleep(0.1)
+    assert fired2 == [] and exits2 == [] and not d2.expired
+    with D.Deadline(0.0, lambda: fired2.append(1), _exit=exits2.append):      # disabled
+        time.sleep(0.05)
+    assert fired2 == [] and exits2 == []
+    # the handler raising must not keep the process alive
+    exits3 = []
+    with D.Deadline(0.05, lambda: 1 / 0, exit_code=3, _exit=exits3.append):
+        time.sleep(0.3)
+    assert exits3 == [3]
