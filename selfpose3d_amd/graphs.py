@@ -18,6 +18,10 @@ class GraphedRootNet:
     (``ProjectLayer.static_camera_table``), so eager calls on the same net keep working with their own ``meta``."""
 
     RING = 4      # slots of the pinned ring: the host may run RING - 1 launches ahead of the GPU
+    # torch.cuda.Event(blocking=True) for the ring slots was measured (tools/experiments/r05_blocking_events.py,
+    # profiles/r05_blocking_events.json): same step time, same host CPU time per step (1.57 ms of the 1.59 ms step either way) -
+    # the host's time is not the event wait.  Left selectable for that script; the default is HIP's own wait.
+    BLOCKING_EVENTS = False
 
     def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3,
                  time_unprojection: bool = False):
@@ -33,7 +37,8 @@ class GraphedRootNet:
         self._batch, self._flip, self._meta, self._dev = B, flip_xcoords, meta, dev
         tab = torch.from_numpy(pack_cameras(meta, B, pl.img_size, flip_xcoords))
         self._ring = torch.empty((self.RING,) + tuple(tab.shape), dtype=torch.float32).pin_memory()
-        self._events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.blocking_events = bool(self.BLOCKING_EVENTS)
+        self._events = [torch.cuda.Event(blocking=self.blocking_events) for _ in range(self.RING)]
         self._counter = torch.zeros(1, dtype=torch.int32, device=dev)      # the kernel's own launch count
         self._launches = 0                                                  # the host's count of fetch launches
         self.cam_dev = torch.empty(tab.shape, dtype=torch.float32, device=dev)
