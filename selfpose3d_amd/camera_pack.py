@@ -93,10 +93,15 @@ def pack_cameras(meta: Sequence[dict], batch: int, img_size: Sequence[int],
     tab = np.zeros((B, V, CAM_STRIDE), np.float32)
     flips = None if flip_xcoords is None else _np(flip_xcoords).astype(bool).reshape(B)
     # one pass over all B x V records (the per-step host cost of a graphed step is this function: the per-view form, ~35
-    # small numpy calls and one 6x6 solve per view, took 0.79 ms for 5 views x 4 samples; this one 0.25 ms)
+    # small numpy calls and one 6x6 solve per view, took 0.79 ms for 5 views x 4 samples; this one 0.3 ms)
 
-    def field(get, width, dtype=np.float32):
-        return np.stack([_np(get(m), dtype).reshape(B, width) for m in meta], 1)          # (B, V, width)
+    def field(get, width, dtype=np.float32):                                              # -> (B, V, width)
+        vals = [get(m) for m in meta]
+        if all(isinstance(v, torch.Tensor) and v.dtype == vals[0].dtype and v.device.type == "cpu" for v in vals):
+            # a DataLoader's collated tensors: ONE stack for the V views instead of V conversions (same values: the cast to
+            # `dtype` happens on the same source numbers either way)
+            return torch.stack([v.detach().reshape(B, width) for v in vals], 1).numpy().astype(dtype, copy=False)
+        return np.stack([_np(v, dtype).reshape(B, width) for v in vals], 1)
     center = field(lambda m: m["center"], 2, np.float64)
     rot = field(lambda m: m["rotation"], 1, np.float64)
     scales = []
