@@ -951,7 +951,14 @@ def main():
             if note is not None:
                 extra["deadline"] = note
             result.setdefault("legs", extra)
-            print(json.dumps(result), flush=True)
+            for attempt in range(5):                 # the deadline thread may serialise while the main thread adds a leg
+                try:
+                    text = json.dumps(result)
+                    break
+                except RuntimeError:
+                    if attempt == 4:
+                        raise
+            print(text, flush=True)
             line_state["printed"] = True
     deadline = D.Deadline(args.leg_deadline if world > 1 else 0.0,
                           lambda: print_line_once(f"legs not finished {args.leg_deadline:.0f} s after the headline measurement: "

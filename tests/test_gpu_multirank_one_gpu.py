@@ -41,3 +41,23 @@ def test_bench_two_ranks_share_one_gpu():
     assert "error" not in ts, ts
     assert ts["n_gpus"] == 2 and ts["allreduce_bytes_per_step"] == ts["gradient_bytes"] > 100e6
     assert ts["find_unused_parameters"] is False and ts["value"] > 0 and ts["loss_last"] == ts["loss_last"]
+
+
+def test_leg_deadline_prints_the_headline_and_every_rank_exits_cleanly():
+    """A leg that does not come back (here: the train leg against a 2-second deadline - its MIOpen warm-up alone takes longer)
+    must not take the headline along: the deadline thread of rank 0 prints the ONE line with what it has, every rank exits with
+    status 0, the launcher returns 0 (bench.py --leg-deadline, distributed.Deadline)."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
+           "--roofline-iters", "20", "--no-cpu-baseline", "--no-cold", "--no-fp32-leg", "--legs", "train_step",
+           "--train-steps", "1", "--train-warmup", "1", "--train-find", "immediate", "--leg-deadline", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-6000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert "deadline" in rec["legs"] and "train_step" not in rec["legs"], rec["legs"]
