@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
             a[1][j][k] = (m1 - m2) - m3;
         }
     const float sh = shift[o];
+    // residual values first (clamped addresses, no predicate): inside the bounds branches below each was a load -> wait ->
+    // store round trip of its own
+    float rv[2][2][2];
+    if (MODE >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int xo = min(2 * tx + i, X - 1), yo = min(2 * ty + j, Y - 1), zo = min(2 * tz + k, Z - 1);
+                    rv[i][j][k] = res[((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o];
+                }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float bq[2][4];
@@ -119,9 +133,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
                 if (zo >= Z) continue;
                 const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o;
                 float v = (k == 0 ? c0 : c1) + sh;
-                if (MODE == 2) v += res[idx];
+                if (MODE == 2) v += rv[i][j][k];
                 if (MODE >= 1) v = fmaxf(v, 0.0f);
-                if (MODE == 3) v += res[idx];
+                if (MODE == 3) v += rv[i][j][k];
                 y[idx] = v;
             }
         }
@@ -344,6 +358,19 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
     const float sh = shift[t];
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
+        // residual values of this output position first, 16 loads in flight (clamped addresses, no predicate): inside the
+        // bounds branch they came out as load -> s_waitcnt vmcnt(0) -> store chains, one memory round trip per element
+        float rv[16];
+        if (MODE >= 2) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 8 * (v >> 2) + (v & 3) + 4 * h;
+                const int rx = row & 3, ry = (row >> 2) & 3, rz = row >> 4;
+                const int xo = min(ox0 + 2 * rx + (a >> 2), X - 1), yo = min(oy0 + 2 * ry + ((a >> 1) & 1), Y - 1);
+                const int zo = min(oz0 + 2 * rz + (a & 1), Z - 1);
+                rv[v] = res[((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t];
+            }
+        }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = 8 * (v >> 2) + (v & 3) + 4 * h;              // tile of this accumulator element
@@ -352,9 +379,9 @@ __global__ __launch_bounds__(64) void wino_fused_kernel(const float *__restrict_
             if (xo < X && yo < Y && zo < Z) {
                 const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t;
                 float val = acc[a][v] + sh;
-                if (MODE == 2) val += res[idx];
+                if (MODE == 2) val += rv[v];
                 if (MODE >= 1) val = fmaxf(val, 0.0f);
-                if (MODE == 3) val += res[idx];
+                if (MODE == 3) val += rv[v];
                 y[idx] = val;
             }
         }
@@ -596,15 +623,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int64_t obase = ((((int64_t)b * X + ox0) * Y + yl) * Z + oz0) * O + t;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
+        float rv[16];                                 // residual values first (see wino_fused_kernel): clamped, unpredicated
+        if (MODE >= 2) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int dx = 2 * (v & 3) + (a >> 2), dy = 4 * ((v >> 2) & 1) + ((a >> 1) & 1), dz = 2 * (v >> 3) + (a & 1);
+                const int xo = min(ox0 + dx, X - 1), yo = min(yl + dy, Y - 1), zo = min(oz0 + dz, Z - 1);
+                rv[v] = res[((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + t];
+            }
+        }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int dx = 2 * (v & 3) + (a >> 2), dy = 4 * ((v >> 2) & 1) + ((a >> 1) & 1), dz = 2 * (v >> 3) + (a & 1);
             if (ox0 + dx < X && oz0 + dz < Z && yl + dy < Y) {
                 const int64_t idx = obase + (((int64_t)dx * Y + dy) * Z + dz) * O;
                 float val = acc[a][v] + sh;
-                if (MODE == 2) val += res[idx];
+                if (MODE == 2) val += rv[v];
                 if (MODE >= 1) val = fmaxf(val, 0.0f);
-                if (MODE == 3) val += res[idx];
+                if (MODE == 3) val += rv[v];
                 y[idx] = val;
             }
         }
@@ -842,10 +878,59 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
     }
 
     // D of the 16x16 MFMA: lane (col = lane & 15, group = lane >> 4) holds tiles 4*group + v, output 16*nb + col
+    if (ox0 + 8 <= X && oy0 + 8 <= Y && oz0 + 2 <= Z) {
+        // interior block (every block of a 40x40x10 or 32^3 grid): one per-lane base address, compile-time offsets, no bounds
+        // branch per element (64 of them cost ~750 instructions per lane, and kept the residual loads apart)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+            const int o = (ow * NBW + n) * 16 + tl;
+            const float sh = shift[o];
+            const int64_t obase = ((((int64_t)b * X + ox0) * Y + oy0) * Z + oz0) * O + o;
+            int off[4];                                                    // tile 4 q + v: (rx, ry) = (v, q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) off[v] = ((2 * v * Y + 2 * q) * Z) * O;
+            float rv[8][4];
+            if (MODE >= 2) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        rv[a][v] = res[obase + off[v] + (((a >> 2) * Y + ((a >> 1) & 1)) * Z + (a & 1)) * O];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float val = acc[a][n][v] + sh;
+                    if (MODE == 2) val += rv[a][v];
+                    if (MODE >= 1) val = fmaxf(val, 0.0f);
+                    if (MODE == 3) val += rv[a][v];
+                    y[obase + off[v] + (((a >> 2) * Y + ((a >> 1) & 1)) * Z + (a & 1)) * O] = val;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
         const int o = (ow * NBW + n) * 16 + tl;
         const float sh = shift[o];
+        // residual values first, all 32 loads of this output group in flight at once: with the load inside the bounds
+        // branch below the compiler emitted branch -> load -> s_waitcnt vmcnt(0) -> store per element, 64 dependent round
+        // trips per lane (MODE 2 cost 8.7 us more than MODE 1 at (4,64,40,40,10)).  The address of an element outside the
+        // volume is clamped into it (never stored), so the loads need no predicate.
+        float rv[8][4];
+        if (MODE >= 2) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int tile = 4 * q + v;
+                    const int rx = tile & 3, ry = tile >> 2;
+                    const int xo = min(ox0 + 2 * rx + (a >> 2), X - 1), yo = min(oy0 + 2 * ry + ((a >> 1) & 1), Y - 1);
+                    const int zo = min(oz0 + (a & 1), Z - 1);
+                    rv[a][v] = res[((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o];
+                }
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #pragma unroll
@@ -856,9 +941,9 @@ __global__ __launch_bounds__(64 * (4 / NBW) * KS) __attribute__((amdgpu_waves_pe
                 if (xo < X && yo < Y && zo < Z) {
                     const int64_t idx = ((((int64_t)b * X + xo) * Y + yo) * Z + zo) * O + o;
                     float val = acc[a][n][v] + sh;
-                    if (MODE == 2) val += res[idx];
+                    if (MODE == 2) val += rv[a][v];
                     if (MODE >= 1) val = fmaxf(val, 0.0f);
-                    if (MODE == 3) val += res[idx];
+                    if (MODE == 3) val += rv[a][v];
                     y[idx] = val;
                 }
             }
