@@ -213,13 +213,21 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_merge_kernel(Cand *__restrict
     for (int base = 0; base < ncand; base += NMS_THREADS * MERGE_PER_THREAD) {
         float mv[MERGE_PER_THREAD];
         unsigned long long mk[MERGE_PER_THREAD];
+        // all of a thread's candidates in flight first - unconditional loads from clamped indices, one basic block - then the
+        // selects: with the load inside `if (i < ncand)` the compiler emitted branch -> load -> s_waitcnt vmcnt(0) per element,
+        // MERGE_PER_THREAD dependent round trips in a kernel of one workgroup per sample
+        Cand cds[MERGE_PER_THREAD];
 #pragma unroll
         for (int e = 0; e < MERGE_PER_THREAD; ++e) {
             const int i = base + e * NMS_THREADS + threadIdx.x;
-            Cand cd; cd.v = -INFINITY; cd.i = 0x7fffffff;
-            if (i < ncand) cd = cand[i];
-            mv[e] = cd.v;
-            mk[e] = cd.i == 0x7fffffff ? 0ull : cand_key(cd.v, cd.i);
+            cds[e] = cand[min(i, ncand - 1)];
+        }
+#pragma unroll
+        for (int e = 0; e < MERGE_PER_THREAD; ++e) {
+            const int i = base + e * NMS_THREADS + threadIdx.x;
+            const bool have = i < ncand && cds[e].i != 0x7fffffff;
+            mv[e] = i < ncand ? cds[e].v : -INFINITY;
+            mk[e] = have ? cand_key(cds[e].v, cds[e].i) : 0ull;
         }
         wave_topk<MERGE_PER_THREAD>(mk, mv, k, skey + wave * SP3D_MAX_TOPK, sval + wave * SP3D_MAX_TOPK);
         __syncthreads();

@@ -144,15 +144,21 @@ __global__ __launch_bounds__(256) void pack_nhwc_kernel(Views hm, float *__restr
     const TI *src = reinterpret_cast<const TI *>(hm.p[v]) + (size_t)b * J * HW;
     TO *packed = reinterpret_cast<TO *>(packed_);
     const int p = p0 + tid;
+    // all J plane loads in flight before the first LDS write: with the load inside `if (p < HW)` the compiler emitted
+    // branch -> load -> s_waitcnt vmcnt(0) -> ds_write per channel, JP dependent round trips per workgroup.  The pixel index is
+    // clamped instead (a lane past the end re-reads the last pixel and writes zero).
+    const int pc = p < HW ? p : HW - 1;
+    float vals[JP];
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
-        float val = 0.0f;
-        if (j < J && p < HW) {
-            if constexpr (sizeof(TI) == 2) val = bf16_to_f32(reinterpret_cast<const uint16_t *>(src)[(size_t)j * HW + p]);
-            else val = reinterpret_cast<const float *>(src)[(size_t)j * HW + p];
+        vals[j] = 0.0f;
+        if (j < J) {                                                   // wave-uniform
+            if constexpr (sizeof(TI) == 2) vals[j] = bf16_to_f32(reinterpret_cast<const uint16_t *>(src)[(size_t)j * HW + pc]);
+            else vals[j] = reinterpret_cast<const float *>(src)[(size_t)j * HW + pc];
         }
-        tile[j][tid] = val;
     }
+#pragma unroll
+    for (int j = 0; j < JP; ++j) tile[j][tid] = p < HW ? vals[j] : 0.0f;
     __syncthreads();
     constexpr int NQ = JP / 4;
     TO *dst = packed + (((size_t)v * B + b) * HW + p0) * JP;
@@ -1223,9 +1229,16 @@ __global__ __launch_bounds__(64) void unproject_bwd2_kernel(const float *__restr
     const bool dead = (mymask & 0x80000000u) != 0 || (mymask & 0x7fffffffu) == 0;
     const float *gc = grad_cubes + (size_t)b * g.J * g.N + n;
     bool any = false;
+    // the J gradient loads of a voxel in flight together (n is a valid voxel for every lane): inside the per-channel condition
+    // they were JP dependent round trips per wave
+    float gl[JP];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) gl[j] = (j < g.J) ? gc[(size_t)j * g.N] : 0.0f;
+    const bool live = inb && !dead;
+#pragma unroll
     for (int j = 0; j < JP; ++j) {
         float v = 0.0f;
-        if (j < g.J && inb && !dead && ((pm >> j) & 1u)) v = gc[(size_t)j * g.N] / den;
+        if (j < g.J && live && ((pm >> j) & 1u)) v = gl[j] / den;
         any = any || (v != 0.0f);
         gt[j * 64 + lane] = v;
     }
