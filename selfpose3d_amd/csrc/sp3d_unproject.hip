@@ -149,13 +149,19 @@ __global__ __launch_bounds__(256) void pack_nhwc_kernel(Views hm, float *__restr
     // clamped instead (a lane past the end re-reads the last pixel and writes zero).
     const int pc = p < HW ? p : HW - 1;
     float vals[JP];
+    // channel index clamped too (planes j >= J re-read plane J - 1 and are zeroed below): straight-line code, no branch between
+    // the loads - behind a wave-uniform `j < J` branch the bf16 variant still waited for every load before widening it
+    if constexpr (sizeof(TI) == 2) {
+        uint32_t raw[JP];
 #pragma unroll
-    for (int j = 0; j < JP; ++j) {
-        vals[j] = 0.0f;
-        if (j < J) {                                                   // wave-uniform
-            if constexpr (sizeof(TI) == 2) vals[j] = bf16_to_f32(reinterpret_cast<const uint16_t *>(src)[(size_t)j * HW + pc]);
-            else vals[j] = reinterpret_cast<const float *>(src)[(size_t)j * HW + pc];
-        }
+        for (int j = 0; j < JP; ++j) raw[j] = (uint32_t)reinterpret_cast<const uint16_t *>(src)[(size_t)min(j, J - 1) * HW + pc];
+#pragma unroll
+        for (int j = 0; j < JP; ++j) vals[j] = j < J ? __uint_as_float(raw[j] << 16) : 0.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < JP; ++j) vals[j] = reinterpret_cast<const float *>(src)[(size_t)min(j, J - 1) * HW + pc];
+#pragma unroll
+        for (int j = 0; j < JP; ++j) vals[j] = j < J ? vals[j] : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < JP; ++j) tile[j][tid] = p < HW ? vals[j] : 0.0f;

@@ -527,3 +527,35 @@ def test_no_packed_instruction_of_either_library_reads_the_high_half_of_source_1
         packed = len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text))
         assert (packed > 10000) if want_packed else (packed == 0), (path, packed)
         assert pk_src1.count_risky(text) == 0, path
+
+
+def test_device_assembly_has_no_load_wait_store_chains_and_no_scratch(lib):
+    """tools/isa_scan.py over the assembly the build keeps: no kernel may contain >= 8 `load -> s_waitcnt vmcnt(0) -> store`
+    chains (the epilogue shape that cost the half-resolution Winograd kernel 9 of its 81 us until round 5,
+    profiles/r05_epilogue_fix.md), none outside the scan's by-design list may wait for most of its loads one at a time, and
+    none may spill registers to scratch memory."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "tools", "isa_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    recs = mod.scan()
+    if len(recs) < 150:                      # library present but its object directory is not (a copied tree): compile again
+        sbuild.build(force=True)
+        recs = mod.scan()
+    assert len(recs) >= 150, "the build keeps its device assembly under selfpose3d_amd/build/obj"
+    bad = [r for r in recs if r["flag"]]
+    assert not bad, bad
+    # the scan does see the pattern: a synthetic kernel body with ten chains is flagged
+    body = ["_ZN4sp3d4fakeEv:"] + ["\tglobal_load_dword v1, v[2:3], off", "\ts_waitcnt vmcnt(0)", "\tv_add_f32 v1, v1, v4",
+                                    "\tglobal_store_dword v[5:6], v1, off"] * 10 + ["; ScratchSize: 0"]
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "fake.s"), "w") as f:
+            f.write("\n".join(body))
+        old = mod.OBJ
+        mod.OBJ = d
+        try:
+            fake = mod.scan()
+        finally:
+            mod.OBJ = old
+    assert len(fake) == 1 and fake[0]["load_wait_store_chains"] == 10 and fake[0]["flag"]
