@@ -1102,11 +1102,7 @@ def main():
         except Exception as e:      # a peer has left (its deadline fired a moment earlier, or it died): the line must still get out
             print_line_once(f"final barrier failed ({type(e).__name__}): a peer rank left before this one")
     deadline.__exit__(None, None, None)
-    if world > 1:
-        try:
-            dist.destroy_process_group()
-        except Exception:
-            pass
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -35,6 +35,25 @@ def init(backend: str | None = None, device: torch.device | None = None):
     return rank, world
 
 
+class _StdoutToStderr:
+    """File-descriptor-level redirect of stdout to stderr while a gloo group connects: the library announces "[Gloo] Rank r is
+    connected to n peer ranks" on the process's STDOUT, and bench.py's contract is that rank 0 prints exactly one line there."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def init_split(data_backend: str = "nccl", single_rank: bool = False):
     """bench.py's process groups: the CONTROL plane (barriers around timed regions, max / sum of a few host numbers) is the
     default group on gloo - host memory, TCP on 127.0.0.1, nothing on the GPU's queues - and the DATA plane (DDP's gradient
@@ -48,9 +67,24 @@ def init_split(data_backend: str = "nccl", single_rank: bool = False):
     if (world > 1 or single_rank) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("gloo")
-        _DATA_GROUP = dist.new_group(backend=data_backend)
+        with _StdoutToStderr():
+            dist.init_process_group("gloo")
+            _DATA_GROUP = dist.new_group(backend=data_backend)
+            dist.barrier()                          # the gloo mesh connects (and says so) here, not inside a timed region
+            if data_backend == "gloo":
+                dist.barrier(group=_DATA_GROUP)
     return rank, world
+
+
+def shutdown():
+    """destroy the process groups of init / init_split (no-op when none exists); never raises - a peer may be gone already"""
+    global _DATA_GROUP
+    _DATA_GROUP = None
+    try:
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
 
 
 def data_group():

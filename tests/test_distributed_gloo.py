@@ -267,7 +267,9 @@ def _split_worker(rank, world, port, q):
     ddp(x).sum().backward()
     q.put((rank, net.weight.grad.tolist()))        # plain lists: a tensor in the queue needs the sender alive
     dist.barrier()
-    dist.destroy_process_group()
+    D.shutdown()
+    assert D.data_group() is None and not dist.is_initialized()
+    D.shutdown()                                   # a second call is a no-op
 
 
 def test_control_plane_on_gloo_data_plane_on_its_own_group():
@@ -306,3 +308,43 @@ def test_deadline_fires_once_and_cancels_cleanly():
     with D.Deadline(0.05, lambda: 1 / 0, exit_code=3, _exit=exits3.append):
         time.sleep(0.3)
     assert exits3 == [3]
+
+
+_ONE_LINE_CHILD = r"""
+import os, socket, sys
+import torch, torch.multiprocessing as mp
+sys.path.insert(0, os.environ["SP3D_ROOT"])
+
+def w(rank, port):
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from selfpose3d_amd import distributed as D
+    import torch.distributed as dist
+    D.init_split("gloo")
+    assert D.max_over_ranks(1.0 + rank) == 2.0
+    ddp = D.wrap_ddp(torch.nn.Linear(2, 2), find_unused=False)
+    ddp(torch.ones(1, 2)).sum().backward()
+    dist.barrier()
+    if rank == 0:
+        print('{"line": 1}', flush=True)
+    D.shutdown()
+
+if __name__ == "__main__":
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(w, args=(port,), nprocs=2)
+"""
+
+
+def test_gloo_control_plane_keeps_stdout_to_the_one_line(tmp_path):
+    """gloo announces "[Gloo] Rank r is connected to n peer ranks" on STDOUT when a group connects; bench.py's contract is ONE line
+    on stdout (rank 0's JSON).  init_split connects its groups with stdout pointed at stderr: two ranks, both groups used, and the
+    only thing on the job's stdout is the line rank 0 printed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / "one_line_child.py"         # a file: mp.spawn pickles the worker by module attribute
+    child.write_text(_ONE_LINE_CHILD)
+    r = subprocess.run([sys.executable, str(child)], env=dict(os.environ, SP3D_ROOT=root), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines() == ['{"line": 1}'], r.stdout
+    assert "[Gloo]" in r.stderr                    # the announcement went to stderr, it was not swallowed

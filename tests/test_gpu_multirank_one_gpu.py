@@ -31,6 +31,9 @@ def test_bench_two_ranks_share_one_gpu():
     assert r.returncode == 0, r.stderr[-6000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints the ONE line
+    # ... and nothing else reaches the job's stdout (gloo announces its connections there: distributed.init_split points
+    # stdout at stderr while the groups connect)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("{")] == [], r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["value"] > 0
     # round 5: ranks that share a GPU load libsp3d_nopk.so (no packed-fp32 instructions), which is immune to the interaction of
