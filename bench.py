@@ -19,6 +19,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with three extra
   cpu_baseline  - the CPU oracle (C port, OpenMP) + torch-CPU V2V on a bounded sample of the same workload, all cores and 1
   cpu_reference - the reference's own Python timed in the build container (static: profiles/cpu_reference.json)
 
+N > 1: barriers and the max over ranks run on a gloo group in host memory, RCCL carries only the DDP gradient buckets of
+legs.train_step (selfpose3d_amd/distributed.py: init_split), so the headline does not depend on RCCL; the legs after the headline
+measurement run under --leg-deadline (600 s): if a collective never returns, rank 0 prints the line it has and every rank exits 0.
+
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
