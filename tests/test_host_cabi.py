@@ -559,3 +559,60 @@ def test_device_assembly_has_no_load_wait_store_chains_and_no_scratch(lib):
         finally:
             mod.OBJ = old
     assert len(fake) == 1 and fake[0]["load_wait_store_chains"] == 10 and fake[0]["flag"]
+
+
+def _pack_cameras_per_view(meta, batch, img_size, flip_xcoords=None):
+    """the camera pack as it was written first - one view at a time, field by field - kept as the yardstick of the batched form"""
+    from selfpose3d_amd import camera_pack as cp
+    V, B = len(meta), int(batch)
+    tab = np.zeros((B, V, cp.CAM_STRIDE), np.float32)
+    flips = None if flip_xcoords is None else cp._np(flip_xcoords).astype(bool).reshape(B)
+    for c in range(V):
+        m = meta[c]
+        cam = m["camera"]
+        center = cp._np(m["center"], np.float64).reshape(B, 2)
+        scale = cp._np(m["scale"]).reshape(B, -1)
+        if scale.shape[1] == 1:
+            scale = np.repeat(scale, 2, 1)
+        rot = cp._np(m["rotation"], np.float64).reshape(B)
+        A = cp.get_affine_transform_batch(center, scale.astype(np.float32), rot, img_size)
+        tab[:, c, cp.CAM_R:cp.CAM_R + 9] = cp._np(cam["R"], np.float32).reshape(B, 9)
+        tab[:, c, cp.CAM_T:cp.CAM_T + 3] = cp._np(cam["T"], np.float32).reshape(B, 3)
+        tab[:, c, cp.CAM_F] = cp._np(cam["fx"], np.float32).reshape(B)
+        tab[:, c, cp.CAM_F + 1] = cp._np(cam["fy"], np.float32).reshape(B)
+        tab[:, c, cp.CAM_C] = cp._np(cam["cx"], np.float32).reshape(B)
+        tab[:, c, cp.CAM_C + 1] = cp._np(cam["cy"], np.float32).reshape(B)
+        tab[:, c, cp.CAM_K:cp.CAM_K + 3] = cp._np(cam["k"], np.float32).reshape(B, 3)
+        tab[:, c, cp.CAM_P:cp.CAM_P + 2] = cp._np(cam["p"], np.float32).reshape(B, 2)
+        tab[:, c, cp.CAM_A:cp.CAM_A + 6] = A.astype(np.float32).reshape(B, 6)
+        tab[:, c, cp.CAM_W0] = (center[:, 0] * 2.0).astype(np.float32)
+        tab[:, c, cp.CAM_H0] = (center[:, 1] * 2.0).astype(np.float32)
+        if flips is not None:
+            tab[:, c, cp.CAM_FLIP] = flips.astype(np.float32)
+    return cp.finish(tab)
+
+
+@pytest.mark.parametrize("B,V", [(4, 5), (1, 3), (2, 10), (3, 4)])
+def test_batched_camera_pack_equals_the_per_view_form_bit_for_bit(B, V):
+    """pack_cameras gathers every field of all views with one stack and solves all B x V crop affines in one call (the per-step
+    host cost of a graphed step); the table must be the per-view form's, byte for byte: augmented crops, flips, scalar scales,
+    numpy entries mixed with tensors (the fallback of the field gather)"""
+    from selfpose3d_amd.camera_pack import pack_cameras
+    cfg = load_config(None)
+    img = [int(v) for v in cfg.NETWORK.IMAGE_SIZE]
+    meta = syn.make_meta(B, V, img)
+    rng = np.random.default_rng(B * 10 + V)
+    for m in meta:
+        m["rotation"] = torch.tensor(rng.uniform(-40, 40, B))
+        m["scale"] = torch.tensor(rng.uniform(3, 9, (B, 2)).astype(np.float32))
+        m["center"] = torch.tensor(rng.uniform(200, 800, (B, 2)))
+    for flip in (None, torch.tensor(rng.integers(0, 2, B).astype(bool))):
+        assert pack_cameras(meta, B, img, flip).tobytes() == _pack_cameras_per_view(meta, B, img, flip).tobytes()
+    for m in meta:
+        m["scale"] = torch.tensor(rng.uniform(3, 9, (B,)).astype(np.float32))          # scalar scale -> [s, s]
+    assert pack_cameras(meta, B, img).tobytes() == _pack_cameras_per_view(meta, B, img).tobytes()
+    for i, m in enumerate(meta):                                                        # numpy entries: the gather falls back
+        m["center"] = m["center"].numpy()
+        if i % 2:
+            m["camera"]["R"] = m["camera"]["R"].numpy()
+    assert pack_cameras(meta, B, img).tobytes() == _pack_cameras_per_view(meta, B, img).tobytes()
