@@ -703,7 +703,8 @@ def test_winograd_conv3d_with_fused_epilogue(dev, shape):
     assert float((y.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 32, (16, 16, 8), 2), (1, 16, (8, 8, 4), 1), (3, 32, (9, 7, 5), 0), (1, 32, (20, 12, 6), 3), (4, 16, (10, 17, 3), 1)])
+@pytest.mark.parametrize("shape", [(2, 32, (16, 16, 8), 2), (1, 16, (8, 8, 4), 1), (3, 32, (9, 7, 5), 0), (1, 32, (20, 12, 6), 3), (4, 16, (10, 17, 3), 1),
+                                   (2, 32, (9, 7, 5), 2)])          # ragged grid + residual: clamped residual addresses (round 5)
 def test_winograd_fused_kernel(dev, shape):
     """sp3d_wino_fused (one launch: on-the-fly transforms + v_mfma_f32_32x32x2_f32 + epilogue) == conv3d + epilogue,
     block-edge and odd sizes included; float64 referee."""
@@ -1057,7 +1058,11 @@ def test_winograd_fused_split_kernel_has_fp32_accuracy(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 64, (16, 16, 4), 1), (1, 32, (9, 7, 5), 2), (1, 64, (8, 8, 2), 3), (2, 32, (24, 8, 6), 0),
-                                   (1, 64, (40, 40, 10), 2)])
+                                   (1, 64, (40, 40, 10), 2),
+                                   # round 5: interior blocks take a branch-free epilogue, edge blocks load their residual from
+                                   # clamped addresses - ragged grids with a residual in both residual modes, and a grid that has
+                                   # interior AND edge blocks
+                                   (1, 64, (10, 9, 3), 3), (2, 64, (12, 10, 5), 2), (1, 32, (20, 17, 4), 3)])
 def test_winograd_fused_split64_kernel(shape):
     """sp3d_wino_fused_split64 (half-resolution layers, 16x16x32 bf16 MFMA, three exact pieces) == conv3d + epilogue vs a
     float64 referee; block-edge and odd sizes included"""
