@@ -34,6 +34,8 @@ class Case:
         w, h = self.hm
         if str(g["hm_kind"]) == "random":
             self.hms = syn.random_heatmaps(self.B, self.V, self.J, h, w, seed=int(g["seed"]))
+        elif str(g["hm_kind"]) == "random_wide":                  # round 6: values outside [0, 1], the clamp blocks gradient
+            self.hms = [x * 2.4 + -0.7 for x in syn.random_heatmaps(self.B, self.V, self.J, h, w, seed=int(g["seed"]))]
         else:
             self.hms, _ = syn.people_heatmaps(self.B, self.V, self.J, h, w, self.img, seed=int(g["seed"]))
         # inputs must be the ones the golden was computed on
@@ -62,7 +64,8 @@ class Case:
 SMALL_CASES = ["unproj_coarse_small", "unproj_coarse_j1_v1", "unproj_coarse_aug", "unproj_fine_small",
                "unproj_grad_small", "unproj_grad_fine_aug"]
 FULL_CASES = ["unproj_coarse_full_96x72", "unproj_coarse_full_240x128", "unproj_fine_full_240x128",
-              "unproj_stress_v10", "unproj_people_coarse"]
+              "unproj_stress_v10", "unproj_people_coarse", "unproj_coarse_b4"]
+GRAD_FULL_CASES = ["unproj_grad_root_full", "unproj_grad_fine_full"]      # round 6: the backward at the sizes it runs at
 
 
 # ---- round 3: model-level training goldens (tests/golden/make_goldens_r3.py) -----------------------------------------
@@ -118,6 +121,22 @@ def he_fill(model, seed):
                 a = 0.05 * rng.standard_normal(tuple(t.shape)).astype(np.float32)
             t.copy_(torch.from_numpy(a))
     return model
+
+
+# ---- round 6: the SSV rendering caught inside the reference's forward (tests/golden/make_goldens_r6.py) -----------------
+RENDER_FULL = dict(img=(960, 512), hm=(240, 128), V=3, J=15, cube=(24, 24, 8), fine_cube=(16, 16, 16), max_people=4,
+                   layers=18, threshold=0.0, sigma=3)
+
+
+def render_cfg():
+    """the small SSV scene at FULL heat-map size (240x128): what render_ssv_full.npz was generated on"""
+    global TRAIN_SMALL
+    keep = TRAIN_SMALL
+    TRAIN_SMALL = RENDER_FULL
+    try:
+        return train_cfg(ssv=True)
+    finally:
+        TRAIN_SMALL = keep
 
 
 # ---- round 4: the pose stage at full size (tests/golden/make_goldens_r4.py) --------------------------------------------

@@ -111,3 +111,60 @@ def test_posenet_full_cubes_golden():
         assert np.abs(got[:, :, g["sub_idx"]] - g[f"cube_sub_{k}"]).max() <= VOX_TOL
         assert np.allclose(got.astype(np.float64).sum(axis=2), g[f"cube_sum_{k}"], rtol=0, atol=1e-7 * N)
         assert np.count_nonzero(cubes[~valid.astype(bool)]) == 0
+
+
+# ---- round 6: the backward (and the B=4 forward) at the sizes the kernels run at ------------------------------------------
+def grad_full_check(got, g, tol_rel=2e-5, what=""):
+    """(V,B,J,h,w) gradient against a full-size golden of tests/golden/make_goldens_r6.py: the stored sub-sample and two
+    whole planes element by element, float64 sums / position-weighted sums per (view, sample, joint), and the exact set
+    of touched pixels per plane.  Shared by tests/test_gpu_bwd_full_size.py."""
+    V, B, J, h, w = got.shape
+    g64 = got.astype(np.float64)
+    scale = max(1.0, float(np.abs(g["grad_sub"]).max()))
+    sub = got.reshape(-1)[::int(g["grad_stride"])]
+    assert np.abs(sub - g["grad_sub"]).max() <= tol_rel * scale, what
+    assert np.abs(got[0, 0, 2] - g["grad_plane_v0_b0_j2"]).max() <= tol_rel * scale, what
+    assert np.abs(got[V - 1, B - 1, J - 1] - g["grad_plane_vl_bl_jl"]).max() <= tol_rel * scale, what
+    # sums over a 30 720-pixel plane of terms each good to tol_rel * scale: bound by the plane's own mass
+    mass = g["grad_abs_sum"]
+    assert np.all(np.abs(g64.sum(axis=(3, 4)) - g["grad_sum"]) <= tol_rel * (mass + 1.0)), what
+    pw = np.random.default_rng(int(g["pos_seed"])).standard_normal((h, w))
+    assert np.all(np.abs((g64 * pw).sum(axis=(3, 4)) - g["grad_pos_sum"]) <= tol_rel * (mass + 1.0)), what
+    assert np.all(np.abs(np.abs(g64).sum(axis=(3, 4)) - mass) <= tol_rel * (mass + 1.0)), what
+    assert np.all(np.abs(np.abs(got).max(axis=(3, 4)) - g["grad_absmax"]) <= tol_rel * scale), what
+
+
+@pytest.mark.parametrize("name", gio.GRAD_FULL_CASES)
+def test_unproject_bwd_golden_full_size(name):
+    """oracle.unproject_bwd (double accumulation, joints split over threads) against the reference's autograd at B=4,
+    80x80x20 and at four 64^3 cubes: values, sums and the EXACT touched-pixel count of every plane"""
+    case = gio.Case(name)
+    g = case.g
+    wgt = np.random.default_rng(int(g["grad_seed"])).standard_normal((case.B, case.J, *case.cube)).astype(np.float32)
+    grads = np.stack(oracle.unproject_bwd([h.numpy() for h in case.hms], case.cam, case.centers, case.valid, wgt,
+                                          case.grid_size, case.cube, case.img))
+    grad_full_check(grads.astype(np.float32), g, what=name)
+    assert np.array_equal((grads != 0).sum(axis=(3, 4)), g["grad_nonzero"])
+    if not bool(g["center_is_list"]):
+        inv = np.flatnonzero(case.valid == 0)
+        assert len(inv) and not grads[:, inv].any()                  # the skipped sample gets no gradient
+    # forward of the same case: clamp populations equal the reference's voxel for voxel (what the pass mask encodes)
+    cubes, _ = oracle.unproject_fwd([h.numpy() for h in case.hms], case.cam, case.centers, case.valid, case.grid_size,
+                                    case.cube, case.img)
+    assert np.array_equal(((cubes > 0) & (cubes < 1)).sum(axis=(2, 3, 4)), g["cubes_interior"])
+    assert np.array_equal((cubes == 1).sum(axis=(2, 3, 4)), g["cubes_at_one"])
+    assert np.abs(cubes.reshape(case.B, case.J, -1)[:, :, g["sub_idx"]] - g["cubes_sub"]).max() <= VOX_TOL
+
+
+def test_oracle_threads_change_no_bit_of_the_backward():
+    case = gio.Case("unproj_grad_fine_aug")
+    wgt = np.random.default_rng(3).standard_normal((case.B, case.J, *case.cube)).astype(np.float32)
+    args = ([h.numpy() for h in case.hms], case.cam, case.centers, case.valid, wgt, case.grid_size, case.cube, case.img)
+    prev = oracle.set_threads(1)
+    try:
+        one = np.stack(oracle.unproject_bwd(*args))
+        oracle.set_threads(max(2, prev))
+        many = np.stack(oracle.unproject_bwd(*args))
+    finally:
+        oracle.set_threads(prev)
+    assert np.array_equal(one, many)

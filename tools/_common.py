@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 import torch
 
 from selfpose3d_amd import distributed as D
+from selfpose3d_amd.checkpoints import init_from_config, load_checkpoint, save_checkpoint  # noqa: F401 (re-exported)
 from selfpose3d_amd.config import load_config
 from selfpose3d_amd.multi_person_posenet import get_multi_person_pose_net
 from selfpose3d_amd.synthetic_dataset import SyntheticPanoptic, SyntheticPanopticSSV
@@ -39,21 +40,3 @@ def make_loader(cfg, frames, batch_per_gpu, rank, world, seed, shuffle, ssv=Fals
     return torch.utils.data.DataLoader(ds, batch_size=batch_per_gpu, shuffle=(shuffle and sampler is None),
                                        sampler=sampler, num_workers=int(cfg.get("WORKERS", 0)), pin_memory=False,
                                        persistent_workers=False)
-
-
-def save_checkpoint(state, is_best, out_dir, filename="checkpoint.pth.tar"):
-    """file names / dict keys of the reference (lib/utils/utils.py:109-115)"""
-    torch.save(state, os.path.join(out_dir, filename))
-    torch.save(state["state_dict"], os.path.join(out_dir, f"model_epoch_{state['epoch']}.pth.tar"))
-    if is_best and "state_dict" in state:
-        torch.save(state["state_dict"], os.path.join(out_dir, "model_best.pth.tar"))
-
-
-def load_checkpoint(model, optimizer, out_dir, filename="checkpoint.pth.tar"):
-    f = os.path.join(out_dir, filename)
-    if not os.path.isfile(f):
-        return 0, 0.0, -1
-    ck = torch.load(f, map_location="cpu")
-    model.load_state_dict(ck["state_dict"])
-    optimizer.load_state_dict(ck["optimizer"])
-    return ck["epoch"], ck.get("precision", 0.0), ck["epoch"] - 1

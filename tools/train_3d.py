@@ -5,7 +5,9 @@ GPU:   torchrun --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/trai
 Replaces single-process nn.DataParallel (/root/reference/tools/train_3d.py:140) with
 DistributedDataParallel over RCCL (gradient all-reduce only); ``TRAIN.BATCH_SIZE`` stays the per-GPU
 batch.  Stage flags (TRAIN_BACKBONE / TRAIN_ONLY_ROOTNET / FREEZE_ROOTNET / USE_GT) select trainable
-parameters as in tools/train_3d.py:48-75; checkpoints keep the reference's names and keys.
+parameters as in tools/train_3d.py:48-75; checkpoints keep the reference's names and keys, and the stage
+hand-off (NETWORK.PRETRAINED_BACKBONE [+ _PSEUDOGT] / INIT_ROOTNET / INIT_ALL, tools/train_3d.py:150-180) is
+selfpose3d_amd.checkpoints.init_from_config.
 The real datasets are not in the image: frames come from SyntheticPanoptic (--frames).
 """
 import argparse
@@ -14,7 +16,7 @@ import os
 
 import torch
 
-from _common import load_checkpoint, make_loader, save_checkpoint, setup
+from _common import init_from_config, load_checkpoint, make_loader, save_checkpoint, setup
 from selfpose3d_amd import distributed as D
 from selfpose3d_amd.engine import train_3d, train_3d_ssv, validate_3d
 from selfpose3d_amd.models import get_multi_person_pose_net, is_ssv
@@ -56,6 +58,10 @@ def main():
         model.use_channels_last(True)
     params = select_trainable(model, cfg)
     optimizer = torch.optim.Adam(params, lr=float(cfg.TRAIN.LR))
+    # stage hand-off (reference tools/train_3d.py:150-180): PRETRAINED_BACKBONE, INIT_ROOTNET, INIT_ALL, then RESUME;
+    # every rank reads the files itself, a named file that is missing raises
+    for what in init_from_config(model, cfg):
+        logger.info(f"=> initialised from NETWORK.{what} = {cfg.NETWORK[what]}")
     start, best, last = (load_checkpoint(model, optimizer, out) if cfg.TRAIN.RESUME else (int(cfg.TRAIN.BEGIN_EPOCH), 0.0, -1))
     ddp = D.wrap_ddp(model, device, find_unused=D.needs_find_unused(cfg))
     sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, list(cfg.TRAIN.LR_STEP), float(cfg.TRAIN.LR_FACTOR),

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--with-ssv", action="store_true")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--random-init", action="store_true",
+                    help="validate untrained weights when no checkpoint exists (plumbing checks only)")
     args, _ = ap.parse_known_args()
     cfg, rank, world, device, out = setup(args.cfg, "validate")
     loader = make_loader(cfg, args.frames, int(cfg.TEST.BATCH_SIZE), rank, world, seed=2, shuffle=False)
@@ -32,8 +34,10 @@ def main():
         logging.info(f"=> load models state {test_file}")
         sd = torch.load(test_file, map_location="cpu")
         model.load_state_dict(sd.get("state_dict", sd))
+    elif args.random_init:
+        logging.warning(f"=> no checkpoint at {test_file}: validating random-init weights (--random-init)")
     else:
-        logging.warning(f"=> no checkpoint at {test_file}: validating random-init weights")
+        raise ValueError(f"Check the model file for testing! ({test_file})")    # reference tools/validate_3d.py:91-92
     if device.type == "cuda":
         model.use_channels_last(True)
     validate_3d(cfg, model, loader, 0, out, with_ssv=args.with_ssv, device=device, max_iters=args.max_iters)
