@@ -21,7 +21,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with three extra
 
 N > 1: barriers and the max over ranks run on a gloo group in host memory, RCCL carries only the DDP gradient buckets of
 legs.train_step (selfpose3d_amd/distributed.py: init_split), so the headline does not depend on RCCL; the legs after the headline
-measurement run under --leg-deadline (600 s): if a collective never returns, rank 0 prints the line it has and every rank exits 0.
+measurement run under --leg-deadline (600 s): if a collective never returns, rank 0 prints the line it has
+(top level: legs_complete / scaling_valid = false) and every rank exits with status 3 - a hang can neither lose the headline nor pass
+as a finished scaling run.  config.rccl_ranks_seen = the sum of an all-reduce of ones on the data-plane communicator (must equal N).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -43,6 +45,9 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+EXIT_LEGS_INCOMPLETE = 3      # world > 1: the line was printed, but a leg hung / failed or RCCL did not span every rank
 
 
 def parse():
@@ -72,8 +77,8 @@ def parse():
                          "for the inference plan's GEMMs, V2VNet.tune_gemms(True); recorded in config.gemm_selection)")
     ap.add_argument("--leg-deadline", type=float, default=600.0,
                     help="world > 1 only: seconds the legs after the headline measurement may take before rank 0 prints the line "
-                         "it has and every rank exits with status 0 (a collective that never returns must not lose the headline); "
-                         "0 disables")
+                         "it has (legs_complete / scaling_valid false) and every rank exits with status 3 (a collective that never "
+                         "returns must not lose the headline - and must not read as a finished scaling run either); 0 disables")
     ap.add_argument("--legs", default="auto",
                     help="extra legs next to the headline: comma list of pose_stage, train_step, planar_handover, unprojection_grids, unprojection_backward, or 'auto' "
                          "(all four: train_step = BASELINE configs[2], at every N) or 'none'")
@@ -687,11 +692,33 @@ def train_step_leg(args, rank, world, dev):
             host = D.host_contention(step, args.train_steps, dev)
         except Exception as e:
             host = {"error": f"{type(e).__name__}: {e}"}
+    nbytes = int(sum(p.numel() for p in params) * 4)
+    comm = None
+    if world > 1:
+        # how much of the gradient all-reduce does the step hide?  (a) the buckets reduced with nothing else running,
+        # (b) the same step with the all-reduce switched off (DDP.no_sync: local gradients; LAST use of this model - the
+        # ranks' parameters drift apart from here).  exposed = step - (b); overlap = 1 - exposed / (a).
+        try:
+            alone = D.allreduce_alone_ms(nbytes, dev)
+
+            def step_local():
+                with ddp.no_sync():
+                    return step()
+            el_l, _ = D.timed_steps(step_local, args.train_steps, 1, dev)
+            ms, ms_l = 1e3 * el / args.train_steps, 1e3 * el_l / args.train_steps
+            exposed = max(0.0, ms - ms_l)
+            comm = {"allreduce_ms": round(alone, 3), "ms_per_step_without_allreduce": round(ms_l, 2),
+                    "exposed_allreduce_ms": round(exposed, 3),
+                    "overlap": round(min(1.0, max(0.0, 1.0 - exposed / alone)), 3) if alone > 0 else None,
+                    "bus_GBps_alone": round(2 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9, 2),
+                    "what": "allreduce_ms: all gradient buckets (32 MB each) reduced back to back with no compute running; "
+                            "ms_per_step_without_allreduce: the same step under DDP.no_sync(); exposed = difference of the two steps"}
+        except Exception as e:
+            comm = {"error": f"{type(e).__name__}: {e}"}
     V = len(inputs)
     persons = int(sum(int(n) for n in meta[0]["num_person"]))
     slots_in_use = int(max(int(n) for n in meta[0]["num_person"]))       # the reference: one pose-net call per slot in use
     pose_calls = 1 if type(model).batch_slots_in_training else slots_in_use  # round 5: all slots in one pass (grouped BatchNorm)
-    nbytes = int(sum(p.numel() for p in params) * 4)
     return {"metric": "multi-view frames/sec, full train step (BASELINE configs[2]), proposals = ground-truth roots",
             "value": round(D.job_throughput(Bt, args.train_steps, el, world), 3), "unit": "frames/s", "n_gpus": world,
             "ms_per_step": round(1e3 * el / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
@@ -701,6 +728,7 @@ def train_step_leg(args, rank, world, dev):
                            if world > 1 else "none (single process)"),
             "host_contention": host,
             "allreduce_bytes_per_step": nbytes if world > 1 else 0, "gradient_bytes": nbytes,
+            "allreduce_ms": None if comm is None else comm.get("allreduce_ms"), "allreduce_overlap": comm,
             "find_unused_parameters": bool(find_unused), "miopen_selection": args.train_find, "pose_net_calls_per_step": pose_calls, "candidate_slots_in_use": slots_in_use, "person_cubes_per_step": persons,
             "backbone_pass": "all views in one channels_last pass, per-view BatchNorm statistics (grouped kernels)",
             "loss_last": float(state["loss"].detach()), "data": "synthetic frames built once per rank, resident on the device",
@@ -944,17 +972,28 @@ def main():
     extra = {}
     # world > 1: everything below may sit in a collective that never returns (the DDP leg is the first place a multi-GPU
     # RCCL communicator of this repo meets hardware).  Every rank arms the same deadline; when it expires rank 0 prints the
-    # line it has (headline measured above + the legs finished so far + what happened) and all ranks leave with status 0.
+    # line it has (headline measured above + the legs finished so far + what happened) and all ranks leave with status EXIT_LEGS_INCOMPLETE.
     import threading
-    line_lock, line_state = threading.Lock(), {"printed": False}
+    line_lock, line_state = threading.Lock(), {"printed": False, "incomplete": None, "rccl_ranks_seen": None}
 
     def print_line_once(note=None):
         with line_lock:
+            if note is not None and line_state["incomplete"] is None:
+                line_state["incomplete"] = note
             if rank != 0 or line_state["printed"]:
                 return
             if note is not None:
                 extra["deadline"] = note
             result.setdefault("legs", extra)
+            # top level, where a driver looks: did every leg return, and may this line be one point of a scaling curve?
+            # (false: the deadline fired, the final barrier failed, a leg recorded an error, or the data-plane communicator
+            # did not span every rank - in each case the process also exits with EXIT_LEGS_INCOMPLETE)
+            failed = [k for k, v in list(extra.items()) if isinstance(v, dict) and "error" in v]
+            result["legs_complete"] = line_state["incomplete"] is None and not failed
+            seen = line_state["rccl_ranks_seen"]
+            result["scaling_valid"] = bool(result["legs_complete"] and (world == 1 or seen == world))
+            if failed:
+                result["legs_failed"] = failed
             for attempt in range(5):                 # the deadline thread may serialise while the main thread adds a leg
                 try:
                     text = json.dumps(result)
@@ -966,8 +1005,26 @@ def main():
             line_state["printed"] = True
     deadline = D.Deadline(args.leg_deadline if world > 1 else 0.0,
                           lambda: print_line_once(f"legs not finished {args.leg_deadline:.0f} s after the headline measurement: "
-                                                  f"line printed by the deadline thread, every rank exits (--leg-deadline)"))
+                                                  f"line printed by the deadline thread, every rank exits with status "
+                                                  f"{EXIT_LEGS_INCOMPLETE} (--leg-deadline)"), exit_code=EXIT_LEGS_INCOMPLETE)
     deadline.__enter__()
+    if world > 1:
+        # first collective of the data-plane communicator (RCCL unless --share-gpu), under the deadline: one all-reduce of
+        # ones.  The line then PROVES how many ranks RCCL spanned; a communicator that cannot be built is an error entry
+        # and an incomplete run, not a hang inside the train leg.
+        import time as _time
+        t_c = _time.perf_counter()
+        try:
+            seen = D.data_ranks_seen(dev)
+            line_state["rccl_ranks_seen"] = seen
+            if rank == 0:
+                result["config"]["rccl_ranks_seen"] = seen
+                result["config"]["data_plane"] = {"backend": "gloo (--share-gpu)" if args.share_gpu else "nccl (RCCL)",
+                                                  "ranks_seen": seen, "first_collective_s": round(_time.perf_counter() - t_c, 3)}
+        except Exception as e:
+            extra["data_plane"] = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                result["config"]["rccl_ranks_seen"] = 0
     if "host_contention" in legs and world == 1:
         # host-side readiness for 8 ranks per node, measured on this 1-GPU box: the headline step (one graph replay + the
         # camera-table pack per step) and, in the train leg, the ~3 500-launch train step, re-timed with this process
@@ -1097,16 +1154,24 @@ def main():
             except Exception as e:
                 extra["unprojection_backward"] = {"error": f"{type(e).__name__}: {e}"}
         result["legs"] = extra
-        print_line_once()
-        if "output_check" in result and not result["output_check"]["ok"]:
-            raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")
     if world > 1:
+        # the final barrier comes BEFORE the line: whether every rank got here is part of what the line says
         try:
             dist.barrier()
         except Exception as e:      # a peer has left (its deadline fired a moment earlier, or it died): the line must still get out
             print_line_once(f"final barrier failed ({type(e).__name__}): a peer rank left before this one")
+    print_line_once()
     deadline.__exit__(None, None, None)
     D.shutdown()
+    if rank == 0 and "output_check" in result and not result["output_check"]["ok"]:
+        raise SystemExit(f"bench.py: the step's output does not match the reference golden: {result['output_check']}")
+    if world > 1:
+        # every rank agrees on the status without another collective: the deadline / barrier note is local knowledge, a leg's
+        # error record is the same exception on every rank (all ranks run the legs alike)
+        bad = line_state["incomplete"] is not None or any(isinstance(v, dict) and "error" in v for v in extra.values()) or \
+            line_state["rccl_ranks_seen"] != world
+        if bad:
+            raise SystemExit(EXIT_LEGS_INCOMPLETE)
 
 
 if __name__ == "__main__":

@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define SP3D_ABI_VERSION 2
+/* ABI history: 3 = sp3d_unproject_bwd_packed[_det] take `int scatter` before `stream`, sp3d_set_bwd_scatter removed (round 5;
+ * the number was bumped in round 6 - a caller built against version 2 must fail sp3d_abi_version(), not pass a stream as `scatter`) */
+#define SP3D_ABI_VERSION 3
 #define SP3D_MAX_VIEWS 16
 #define SP3D_MAX_TOPK 32
 

@@ -25,7 +25,7 @@ OUT_BF16 = 0x400
 SCATTER_AUTO, SCATTER_PER_TAP, SCATTER_MERGE = 0, 2, 3      # include/sp3d.h: per-call scatter choice of unproject_bwd_packed
 MAX_VIEWS = 16
 MAX_TOPK = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
@@ -42,7 +42,8 @@ class Sp3dError(RuntimeError):
 
 
 def shared_gpu() -> bool:
-    """SP3D_SHARED_GPU=1 (or, when the variable is unset, more local ranks than GPUs): this process is not alone on its GPU (another process, or a second stream of its own, may run
+    """SP3D_SHARED_GPU=1 (or, when the variable is unset and NO *_VISIBLE_DEVICES variable narrows what this process sees,
+    more local ranks than GPUs): this process is not alone on its GPU (another process, or a second stream of its own, may run
     kernels at the same time).  The conservative library flavour is loaded then, libsp3d_nopk.so - no packed-fp32
     instruction at all.  Background (profiles/r05_mfma_pk_hazard.md): ONE packed-fp32 instruction form is wrong on MI355X
     while another kernel's double-rate matrix instructions run on the same CU; the build removes that form from the default
@@ -50,7 +51,12 @@ def shared_gpu() -> bool:
     v = os.environ.get("SP3D_SHARED_GPU")
     if v is not None:
         return v.lower() in ("1", "true", "yes", "on")
-    # not told: a launcher that starts more local ranks than there are GPUs (torchrun's LOCAL_WORLD_SIZE) makes ranks share
+    # not told: a launcher that starts more local ranks than there are GPUs (torchrun's LOCAL_WORLD_SIZE) makes ranks share.
+    # Only when the device count is the NODE's: a launcher that hands every rank one GPU through HIP_/CUDA_/ROCR_VISIBLE_DEVICES
+    # makes device_count() == 1 on a perfectly normal one-process-per-GPU job (round-5 advice) - nothing can be inferred then.
+    if any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                                          "GPU_DEVICE_ORDINAL")):
+        return False
     try:
         ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
         if ranks > 1 and torch.cuda.is_available() and ranks > torch.cuda.device_count():

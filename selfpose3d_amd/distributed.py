@@ -92,6 +92,44 @@ def data_group():
     return _DATA_GROUP
 
 
+def data_ranks_seen(device=None) -> int:
+    """all-reduce(SUM) of a one on the DATA group: how many ranks the communicator gradients travel on really spans.
+    On "nccl" this is the first collective of the RCCL communicator (it is built here); proof for a bench line that RCCL
+    saw N ranks, and the place a broken fabric shows up before the train leg depends on it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1
+    group = _DATA_GROUP
+    on_host = (dist.get_backend(group) if group is not None else dist.get_backend()) == "gloo" and \
+        (device is None or device.type != "cuda")
+    t = torch.ones(1, dtype=torch.float32, device="cpu" if on_host or device is None else device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    return int(round(float(t.item())))
+
+
+def allreduce_alone_ms(nbytes: int, device, bucket_bytes: int = 32 << 20, reps: int = 5, warmup: int = 2) -> float:
+    """milliseconds to all-reduce `nbytes` of fp32 gradients in DDP-sized buckets on the data group with NOTHING else
+    running (no backward to hide behind): the yardstick for how much of the collective a train step overlaps"""
+    import time
+    n = max(1, int(nbytes) // 4)
+    per = max(1, bucket_bytes // 4)
+    buckets = [torch.zeros(min(per, n - i), dtype=torch.float32, device=device) for i in range(0, n, per)]
+
+    def once():
+        works = [dist.all_reduce(b, group=_DATA_GROUP, async_op=True) for b in buckets]
+        for w in works:
+            w.wait()
+    for _ in range(warmup):
+        once()
+    barrier_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    barrier_sync(device)
+    return 1e3 * max_over_ranks(time.perf_counter() - t0, device) / reps
+
+
 def _host_group() -> bool:
     """is the default group a host-memory one (gloo)?  Then the few numbers the timing rule exchanges stay on the host."""
     try:
@@ -190,6 +228,16 @@ def timed_steps_host(step, steps: int, device=None):
     return max_over_ranks(time.perf_counter() - t0, device), c1 - c0, time.process_time() - p0
 
 
+def _die_with_parent():
+    """preexec hook of a child process: SIGKILL it when the parent dies (Linux PR_SET_PDEATHSIG = 1)"""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+    except Exception:
+        pass
+
+
 class HostShare:
     """Put THIS process where one of 8 ranks of a node would live: all its threads pinned to 1/8 of the host's cores
     (the first share), one compute thread (OMP_NUM_THREADS=1) - and, with ``burners``, 7 neighbour "ranks" beside it: on each
@@ -201,8 +249,9 @@ class HostShare:
     a core with this process: the box's container has a CPU quota, which the spinners exhaust for everybody.  Recorded in
     DESIGN.md; eight real ranks need ~16 cores, not 256.)"""
 
-    def __init__(self, burners: bool = False, shares: int = 8, busy_per_rank: int = 2):
-        self.burners, self.shares, self.busy_per_rank = burners, shares, busy_per_rank
+    def __init__(self, burners: bool = False, shares: int = 8, busy_per_rank: int = 2, max_seconds: int = 600):
+        self.burners, self.shares, self.busy_per_rank, self.max_seconds = burners, shares, busy_per_rank, int(max_seconds)
+        self.procs_started = 0
         self.procs, self.prev, self.prev_threads = [], {}, None
 
     @staticmethod
@@ -230,16 +279,33 @@ class HostShare:
                 share = cores[r * per:(r + 1) * per] or cores[-1:]
                 for k in range(self.busy_per_rank):
                     c = share[k % len(share)]
-                    self.procs.append(subprocess.Popen(["taskset", "-c", str(c), "sh", "-c", "while :; do :; done"],
-                                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+                    # a spinner must not outlive this process however it ends (SIGKILL, a timeout of the caller): the kernel
+                    # sends it SIGKILL when its parent dies (PR_SET_PDEATHSIG survives taskset's and bash's exec; no fork in
+                    # between, so the Popen pid IS the spinner), and the loop ends by itself after max_seconds regardless
+                    self.procs.append(subprocess.Popen(["taskset", "-c", str(c), "bash", "-c",
+                                                        f"while [ $SECONDS -lt {self.max_seconds} ]; do :; done"],
+                                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                                       preexec_fn=_die_with_parent))
+            import atexit
+            atexit.register(self._kill)
         return self
+
+    def _kill(self):
+        for p in self.procs:                                   # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                pass
+        self.procs = [p for p in self.procs if p.poll() is None]
 
     def __exit__(self, *exc):
         import os
-        for p in self.procs:                                   # exactly the processes started above
-            p.kill()
-        for p in self.procs:
-            p.wait()
+        n = len(self.procs)
+        self._kill()
+        self.procs_started = n
         for tid, mask in self.prev.items():
             try:
                 os.sched_setaffinity(tid, mask)
@@ -277,7 +343,8 @@ def host_contention(step, steps: int, device=None, base_ms=None):
             with ctx:
                 timed_steps_host(step, max(2, steps // 4), device)          # settle on the new cores
                 el, cpu_t, cpu_p = timed_steps_host(step, steps, device)
-                rec = {"cores": ctx.cores_used, "of": ctx.cores_total, "burner_processes": len(ctx.procs)}
+                n_burn = len(ctx.procs)
+                rec = {"cores": ctx.cores_used, "of": ctx.cores_total, "burner_processes": n_burn}
         rec.update({"ms_per_step": round(1e3 * el / steps, 4), "host_ms_per_step": round(1e3 * cpu_t / steps, 4),
                     "process_cpu_ms_per_step": round(1e3 * cpu_p / steps, 4), "steps": steps})
         out[name] = rec

@@ -114,3 +114,39 @@ def test_host_share_pins_restores_and_cleans_up():
     for r in (v for v in rec.values() if isinstance(v, dict)):
         assert r["ms_per_step"] > 0 and r["host_ms_per_step"] > 0 and "vs_unconstrained" in r
     assert os.sched_getaffinity(0) == before
+
+
+def test_burners_die_with_their_parent():
+    """round-5 advice: a bench.py killed inside legs.host_contention left 14 endless spinners behind.  A child process that
+    enters HostShare(burners=True) and is then SIGKILLed: its spinners are gone within a moment (PR_SET_PDEATHSIG), and a
+    spinner left to itself ends after max_seconds"""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from selfpose3d_amd import distributed as D\n"
+            "h = D.HostShare(burners=True, max_seconds=120).__enter__()\n"
+            "print(' '.join(str(p.pid) for p in h.procs), flush=True)\n"
+            "time.sleep(600)\n" % ROOT)
+    child = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    try:
+        pids = [int(x) for x in child.stdout.readline().split()]
+        assert len(pids) == 14 and all(os.path.exists(f"/proc/{p}") for p in pids)
+        os.kill(child.pid, signal.SIGKILL)                       # exactly the process started above
+        child.wait(timeout=10)
+        deadline = time.time() + 10
+        while time.time() < deadline and any(os.path.exists(f"/proc/{p}") for p in pids):
+            time.sleep(0.1)
+        assert not any(os.path.exists(f"/proc/{p}") for p in pids), "spinners outlived their parent"
+    finally:
+        if child.poll() is None:
+            child.kill()
+    from selfpose3d_amd import distributed as D
+    t0 = time.time()
+    with D.HostShare(burners=True, max_seconds=1) as h:
+        while time.time() - t0 < 8 and any(p.poll() is None for p in h.procs):
+            time.sleep(0.1)
+        assert all(p.poll() is not None for p in h.procs), "a spinner ignored its own time bound"
