@@ -312,6 +312,22 @@ int sp3d_zdft_fwd_cl(const float *x, float *spec, int B, int C, int Cout, int X,
 int sp3d_zdft_inv_cl(const float *spec, float *y, const float *shift, int B, int O, int X, int Y, int Z, int SX, int SY, int SZ,
                      int relu, void *stream);
 
+/* Round 6: the root grid's unprojection FUSED with that z pass (replaces sp3d_unproject_fwd + sp3d_zdft_fwd_cl on the
+ * inference path; reference: lib/models/project_layer.py:42-102 followed by the 7x7x7 opening conv of
+ * lib/models/v2v_net.py:113-117).  A workgroup owns a 4 x 4 bundle of z columns (all Z = 20 voxels, all J channels), keeps
+ * the fused values in LDS and stores their z-spectrum instead of the cubes:
+ *   sp3d_unproject_fwd_zdft: same inputs as sp3d_unproject_fwd with hm_layout = SP3D_LAYOUT_NHWC, Jp = 16 ->
+ *     spec (B, J, SZ/2+1, X/4, Y/4, 16) complex64: per (b, channel, kz) plane the 4 x 4 tiles in row-major tile order,
+ *     inside a tile position 4 * (x % 4) + (y % 4) - every store is one whole 128-byte line; NO zero padding is stored.
+ *     Values are bit-identical to sp3d_zdft_fwd_cl applied to sp3d_unproject_fwd's channels-last cubes.  Samples with
+ *     valid == 0 give all-zero spectra.  Built for (Z,SZ) = (20,28), Jp = 16, X % 4 == Y % 4 == 0; spec 128-byte aligned.
+ *   sp3d_cfft2d_88_tiled: the forward x,y pass reading that layout: tiled (batch, X/4, Y/4, 16) -> planes (batch,88,88)
+ *     complex, = sp3d_cfft2d_ex(forward, rows_in = X) of the zero-padded planes, un-tiling while it loads. */
+int sp3d_unproject_fwd_zdft(const float *const *hm_views, int Jp, const float *cam, const float *centers,
+                            const uint8_t *valid, float *spec, int B, int V, int J, int h, int w, int X, int Y, int Z,
+                            const float grid_size[3], int W_in, int H_in, int SZ, void *stream);
+int sp3d_cfft2d_88_tiled(const float *tiled, float *planes, int batch, int X, int Y, void *stream);
+
 /*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D

@@ -30,7 +30,7 @@ ABI_VERSION = 3
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_soft_argmax_grid", "sp3d_soft_argmax_grid_train", "sp3d_soft_argmax_grid_bwd", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_unproject_fwd_zdft", "sp3d_cfft2d_88_tiled", "sp3d_soft_argmax_grid", "sp3d_soft_argmax_grid_train", "sp3d_soft_argmax_grid_bwd", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
 ]
 
@@ -499,6 +499,44 @@ def zdft_fwd_cl(x: torch.Tensor, cout: int, S) -> torch.Tensor:
     check(lib.sp3d_zdft_fwd_cl(x.data_ptr(), spec.data_ptr(), B, Cc, int(cout), X, Y, Z, SX, SY, SZ, _stream(x.device)),
           "sp3d_zdft_fwd_cl")
     return spec
+
+
+def unproject_fwd_zdft(views: Sequence[torch.Tensor], jp: int, cam: torch.Tensor, centers: torch.Tensor, valid: torch.Tensor,
+                       batch: int, J: int, h: int, w: int, cube_size, grid_size, img_size, SZ: int) -> torch.Tensor:
+    """root grid, inference: the unprojection's result as the z-spectrum of its cubes (include/sp3d.h,
+    sp3d_unproject_fwd_zdft) -> (B, J, SZ//2+1, X/4, Y/4, 16) complex64, 4 x 4-tiled planes without padding"""
+    lib = load()
+    _require_cam(cam)
+    X, Y, Z = (int(c) for c in cube_size)
+    for v in views:
+        _require_cuda(v, "heat-map view")
+        if v.dtype != torch.float32 or not v.is_contiguous() or tuple(v.shape) != (batch, h, w, jp):
+            raise Sp3dError("unproject_fwd_zdft: dense fp32 (B,h,w,16) heat-map views expected")
+    if (Z, int(SZ), jp) not in ZDFT_SHAPES or X % 4 or Y % 4:
+        raise Sp3dError(f"unproject_fwd_zdft: built for (Z, SZ, channels) in {sorted(ZDFT_SHAPES)} and X, Y multiples of 4")
+    spec = torch.empty((batch, J, int(SZ) // 2 + 1, X // 4, Y // 4, 16), dtype=torch.complex64, device=cam.device)
+    lib.sp3d_unproject_fwd_zdft.restype = C.c_int
+    lib.sp3d_unproject_fwd_zdft.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 8 + [C.c_void_p, C.c_int, C.c_int,
+                                                                                                   C.c_int, C.c_void_p]
+    check(lib.sp3d_unproject_fwd_zdft(_ptr_array(views), jp, cam.data_ptr(), centers.data_ptr(), valid.data_ptr(),
+                                      spec.data_ptr(), batch, len(views), J, h, w, X, Y, Z, _f3(grid_size), int(img_size[0]),
+                                      int(img_size[1]), int(SZ), _stream(cam.device)), "sp3d_unproject_fwd_zdft")
+    return spec
+
+
+def cfft2d_88_tiled(spec: torch.Tensor, X: int, Y: int) -> torch.Tensor:
+    """(..., X/4, Y/4, 16) complex64 tiled planes -> (..., 88, 88) complex64: forward x,y transform of the zero-padded planes"""
+    lib = load()
+    _require_cuda(spec, "spec")
+    if spec.dtype != torch.complex64 or not spec.is_contiguous() or tuple(spec.shape[-3:]) != (X // 4, Y // 4, 16):
+        raise Sp3dError("cfft2d_88_tiled: dense complex64 (..., X/4, Y/4, 16) expected")
+    out = torch.empty(tuple(spec.shape[:-3]) + (88, 88), dtype=torch.complex64, device=spec.device)
+    batch = out.numel() // (88 * 88)
+    lib.sp3d_cfft2d_88_tiled.restype = C.c_int
+    lib.sp3d_cfft2d_88_tiled.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    check(lib.sp3d_cfft2d_88_tiled(spec.data_ptr(), out.data_ptr(), batch, int(X), int(Y), _stream(spec.device)),
+          "sp3d_cfft2d_88_tiled")
+    return out
 
 
 def zdft_inv_cl(spec: torch.Tensor, X: int, Y: int, Z: int, SZ: int, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:

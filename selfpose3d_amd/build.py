@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["sp3d_unproject.hip", "sp3d_proposal.hip", "sp3d_epilogue.hip", "sp3d_synth.hip", "sp3d_fftconv.hip", "sp3d_winograd.hip", "sp3d_fft.hip", "sp3d_gbn.hip"]
-HEADERS = [os.path.join("..", "pk_src1.py"), "sp3d_device.h", "sp3d_proj_pk.h", "sp3d_tuning.h", os.path.join("..", "..", "include", "sp3d.h")]
+HEADERS = [os.path.join("..", "pk_src1.py"), "sp3d_device.h", "sp3d_proj_pk.h", "sp3d_tuning.h", "sp3d_twiddles.h", os.path.join("..", "..", "include", "sp3d.h")]
 LIB = os.path.join(HERE, "libsp3d.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",

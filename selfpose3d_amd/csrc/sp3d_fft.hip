@@ -19,6 +19,7 @@
 #include <tuple>
 
 #include "../../include/sp3d.h"
+#include "sp3d_twiddles.h"
 
 namespace {
 // device, stream, kind (0 R2C 3-D, 1 C2R 3-D, 2 C2C 2-D), batch, SX, SY, SZ
@@ -121,24 +122,6 @@ extern "C" int sp3d_cfft2d(float *data, int batch, int SX, int SY, int inverse, 
 //   spectrum layout: (B, C, SZ/2+1, SX, SY) complex
 // ---------------------------------------------------------------------------------------------------------------
 namespace sp3d {
-
-constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr double cx_sin(double x) { double x2 = x * x, t = x, s = x; for (int n = 1; n < 16; ++n) { t *= -x2 / ((2.0 * n) * (2.0 * n + 1.0)); s += t; } return s; }
-constexpr double cx_cos(double x) { double x2 = x * x, t = 1.0, s = 1.0; for (int n = 1; n < 16; ++n) { t *= -x2 / ((2.0 * n - 1.0) * (2.0 * n)); s += t; } return s; }
-template <int SZ> struct Twiddles {
-    float c[SZ], s[SZ];
-    constexpr Twiddles() : c(), s()
-    {
-        for (int m = 0; m < SZ; ++m) {
-            double a = 2.0 * kPi * m / SZ;
-            if (a > kPi) a -= 2.0 * kPi;
-            double cv = cx_cos(a), sv = cx_sin(a);
-            if (cv < 1e-13 && cv > -1e-13) cv = 0.0;
-            if (sv < 1e-13 && sv > -1e-13) sv = 0.0;
-            c[m] = (float)cv; s[m] = (float)sv;
-        }
-    }
-};
 
 constexpr int ZD_TY = 16;                                 // y rows per workgroup
 template <int Z, int C> constexpr int zd_pitch() { return Z * C + 4; }
@@ -341,7 +324,11 @@ __device__ __forceinline__ void f88_pass(float2 *pl, const float2 *tws, int tid,
 
 // rows_in: only the first rows_in rows of every input plane are non-zero (forward transform of zero-padded data; the
 // others are not even read); rows_out: only the first rows_out rows of the result are needed (the others are not written)
-__global__ __launch_bounds__(F88_NT) void cfft2d_88_kernel(float2 *__restrict__ data, int inverse, int rows_in, int rows_out)
+// tiled != nullptr (forward only): the plane's signal comes from the 4 x 4-tiled z-spectrum the fused unprojection kernel
+// writes (sp3d_unproject_fwd_zdft: per plane (rows_in/4, nby, 16) complex, tile-major, no padding) instead of from `data`;
+// the zero padding (columns >= 4 * nby, rows >= rows_in) is produced here.  Every 128-byte line read is one tile.
+__global__ __launch_bounds__(F88_NT) void cfft2d_88_kernel(float2 *__restrict__ data, int inverse, int rows_in, int rows_out,
+                                                           const float2 *__restrict__ tiled, int nby)
 {
     extern __shared__ float2 lds88[];
     float2 *pl = lds88, *tws = lds88 + F88 * F88_PITCH;
@@ -349,6 +336,20 @@ __global__ __launch_bounds__(F88_NT) void cfft2d_88_kernel(float2 *__restrict__ 
     const int tid = threadIdx.x;
     float2 *base = data + (int64_t)blockIdx.x * F88 * F88;
     if (tid < F88) tws[tid] = make_float2(t88.c[tid], -t88.s[tid]);
+    if (tiled) {
+        for (int i = tid; i < F88 * F88_PITCH; i += F88_NT) pl[i] = make_float2(0.0f, 0.0f);
+        __syncthreads();
+        const int ntile = (rows_in / 4) * nby;
+        const float4 *src = reinterpret_cast<const float4 *>(tiled + (int64_t)blockIdx.x * ntile * 16);
+        for (int i = tid; i < ntile * 8; i += F88_NT) {          // 8 float4 (= 2 complex each) per tile
+            const int tile = i >> 3, w = i & 7;
+            const int tx = tile / nby, ty = tile - tx * nby;
+            const int rr = 4 * tx + (w >> 1), cc = 4 * ty + 2 * (w & 1);
+            const float4 v = src[i];
+            pl[rr * F88_PITCH + cc] = make_float2(v.x, v.y);
+            pl[rr * F88_PITCH + cc + 1] = make_float2(v.z, v.w);
+        }
+    } else
     for (int i = tid; i < F88 * F88 / 2; i += F88_NT) {
         const int e = 2 * i, rr = e / F88, cc = e - rr * F88;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -403,6 +404,20 @@ extern "C" int sp3d_zdft_inv_cl(const float *spec, float *y, const float *shift,
     return e == hipSuccess ? SP3D_OK : (int)e;
 }
 
+// dynamic LDS of cfft2d_88_kernel (a plane + the twiddle row: 63 KB, above the default limit: raised once per process)
+static int f88_lds(size_t *bytes)
+{
+    *bytes = (size_t)(sp3d::F88 * sp3d::F88_PITCH + sp3d::F88) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(sp3d::cfft2d_88_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes);
+        if (ea != hipSuccess) return (int)ea;
+        attr_set = true;
+    }
+    return SP3D_OK;
+}
+
 // sp3d_cfft2d with the zero-padding knowledge of its caller: only the first rows_in rows (x) of every input plane are
 // non-zero, only the first rows_out rows of every output plane are needed.  88 x 88 planes run in the single-kernel LDS
 // transform above; other sizes fall back to the hipFFT plan (full planes).
@@ -412,16 +427,27 @@ extern "C" int sp3d_cfft2d_ex(float *data, int batch, int SX, int SY, int invers
     if (!data) return SP3D_ENULL;
     if (SX != sp3d::F88 || SY != sp3d::F88 || (reinterpret_cast<uintptr_t>(data) & 15))
         return sp3d_cfft2d(data, batch, SX, SY, inverse, stream);
-    const size_t lds = (size_t)(sp3d::F88 * sp3d::F88_PITCH + sp3d::F88) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(sp3d::cfft2d_88_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) return (int)ea;
-        attr_set = true;
-    }
+    size_t lds;
+    if (const int ra = f88_lds(&lds)) return ra;
     hipLaunchKernelGGL(sp3d::cfft2d_88_kernel, dim3((unsigned)batch), dim3(sp3d::F88_NT), lds, (hipStream_t)stream,
-                       reinterpret_cast<float2 *>(data), inverse, rows_in, rows_out);
+                       reinterpret_cast<float2 *>(data), inverse, rows_in, rows_out, (const float2 *)nullptr, 0);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SP3D_OK : (int)e;
+}
+
+// forward 88 x 88 plane transforms whose input is the 4 x 4-tiled z-spectrum of sp3d_unproject_fwd_zdft:
+// tiled (batch, X/4, Y/4, 16) complex -> planes (batch, 88, 88) complex (all 88 rows written)
+extern "C" int sp3d_cfft2d_88_tiled(const float *tiled, float *planes, int batch, int X, int Y, void *stream)
+{
+    if (batch <= 0 || X <= 0 || Y <= 0) return SP3D_EINVAL;
+    if (!tiled || !planes) return SP3D_ENULL;
+    if ((X & 3) || (Y & 3) || X > sp3d::F88 || Y > sp3d::F88 || (reinterpret_cast<uintptr_t>(tiled) & 15) ||
+        (reinterpret_cast<uintptr_t>(planes) & 15))
+        return SP3D_EUNSUPPORTED;
+    size_t lds;
+    if (const int ra = f88_lds(&lds)) return ra;
+    hipLaunchKernelGGL(sp3d::cfft2d_88_kernel, dim3((unsigned)batch), dim3(sp3d::F88_NT), lds, (hipStream_t)stream,
+                       reinterpret_cast<float2 *>(planes), 0, X, sp3d::F88, reinterpret_cast<const float2 *>(tiled), Y / 4);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SP3D_OK : (int)e;
 }

@@ -23,6 +23,7 @@
 #include <string.h>
 #include "sp3d_device.h"
 #include "sp3d_proj_pk.h"
+#include "sp3d_twiddles.h"
 
 namespace sp3d {
 
@@ -692,7 +693,15 @@ constexpr int BR = 4;
 #ifndef SP3D_BRICK_MINW
 #define SP3D_BRICK_MINW 4
 #endif
-template <int JP, bool OUTCL, typename TI = float, typename TO = float>
+// ZD (round 6, root grid only: Z == ZDZ voxels = the whole z extent in ONE stack, JP == 16, float in / out): the workgroup
+// does not store its cubes at all.  Its 4 x 4 columns x Z x J values stay in LDS and leave as the z-SPECTRUM the opening
+// 7^3 conv wants (the direct ZDZ -> ZDSZ/2+1 point DFT of zdft_fwd_cl_kernel, sp3d_fft.hip: same table, same FMA order,
+// same bits), in a layout whose unit is this workgroup's 4 x 4 tile: (B, J, K, X/4, Y/4, 16) complex, so every store is
+// one whole 128-byte line.  `cubes` then points at that spectrum.  Deletes the cubes' write + re-read (2 x 32.8 MB at
+// B = 4) and one launch from the root-net step; cfft2d_88_kernel un-tiles while it loads a plane into LDS.
+constexpr int ZDZ = 20, ZDSZ = 28;
+constexpr int SP3D_VARIANT_ZD = 1 << 24;        // launch_nhwc `variant` bit: brick stacks emit the z-spectrum
+template <int JP, bool OUTCL, typename TI = float, typename TO = float, bool ZD = false>
 __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
                                                                 const float *__restrict__ centers,
                                                                 const uint8_t *__restrict__ valid,
@@ -732,7 +741,8 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
     const bool ginb = gy < g.Y && gz < g.Z;
     const int gn0 = (x0 * g.Y + min(gy, g.Y - 1)) * g.Z + min(gz, g.Z - 1);        // + i * YZ
 
-    if (!valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
+    const bool dead = ZD && !valid[b];      // ZD: a skipped sample's workgroups still emit their (all-zero) spectrum lines
+    if (!ZD && !valid[b]) { // skipped sample: zeros (project_layer.py:48,51,54)
         if (inb) {
             const size_t zo = (size_t)vx * g.sX + (size_t)vy * g.sY + vz;
             for (int j = 0; j < g.J; ++j)
@@ -746,7 +756,9 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
         return;
     }
 
-    if (z0 < g.Z) {      // (a stack's last waves may lie above the volume: they only join the barrier)
+    if (dead) {
+        for (int i = lane; i < JP * WOSTR; i += 64) ws[i] = 0.0f;
+    } else if (z0 < g.Z) {      // (a stack's last waves may lie above the volume: they only join the barrier)
         const float x = linspace_step(g.Lx, g.stepx, g.X, min(vx, g.X - 1)) + centers[3 * b + 0];
         const float y = linspace_step(g.Ly, g.stepy, g.Y, min(vy, g.Y - 1)) + centers[3 * b + 1];
         const float z = linspace_step(g.Lz, g.stepz, g.Z, min(vz, g.Z - 1)) + centers[3 * b + 2];
@@ -820,6 +832,34 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
     }
     if (OUTCL) return;
     __syncthreads();
+    if constexpr (ZD) {
+        // thread -> (column pos = 4 * lx + ly of the tile, channel c): a wave holds 4 channels x 16 columns, its 16-lane groups
+        // store 16 complex values = one 128-byte line per (c, kz)
+        constexpr int K = ZDSZ / 2 + 1;
+        constexpr Twiddles<ZDSZ> tw{};
+        const int pos = tid & 15, c = tid >> 4;
+        if (c >= g.J) return;
+        float v[ZDZ];
+#pragma unroll
+        for (int wz = 0; wz < ZDZ / BR; ++wz) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(bsmem + wz * WLDS + c * WOSTR + pos * 4);
+            v[4 * wz] = q4.x; v[4 * wz + 1] = q4.y; v[4 * wz + 2] = q4.z; v[4 * wz + 3] = q4.w;
+        }
+        float2 *o = reinterpret_cast<float2 *>(cubes) + ((((size_t)b * g.J + c) * K) * (size_t)g.bk_nxy + (size_t)t) * 16 + pos;
+        const size_t kstride = (size_t)g.bk_nxy * 16;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float re = 0.0f, im = 0.0f;
+#pragma unroll
+            for (int z = 0; z < ZDZ; ++z) {
+                const int m = (k * z) % ZDSZ;
+                re = fmaf(v[z], tw.c[m], re);
+                im = fmaf(v[z], -tw.s[m], im);
+            }
+            o[(size_t)k * kstride] = make_float2(re, im);
+        }
+        return;
+    }
     // workgroup store of the (J, 4, 4, 4*zw) block: thread -> (channel phase jj, column, brick of the stack)
     const float rzw = 1.0f / (float)zw;
     const int per = 16 * zw;                                       // (column, brick) pairs = threads per channel phase
@@ -1606,6 +1646,17 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
             }
         }
         dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
+        if (variant & SP3D_VARIANT_ZD) {   // the stack's cubes leave as their z-spectrum (sp3d_unproject_fwd_zdft)
+            if constexpr (JP == 16) {
+                if (io || out_cl || grids || g.Z != ZDZ || nzc != 1 || zw != ZDZ / BR || (g.X % BR) || (g.Y % BR) || g.pass_mask)
+                    return SP3D_EUNSUPPORTED;
+                hipLaunchKernelGGL((unproject_brick_kernel<16, false, float, float, true>), bgrid, bblock, blds, s, v, cam, centers,
+                                   valid, cubes, grids, gb, wgs, nby, nzc, zw);
+                return SP3D_OK;
+            } else {
+                return SP3D_EUNSUPPORTED;
+            }
+        }
 #define SP3D_BRICK(CL_, TI_, TO_) \
     hipLaunchKernelGGL((unproject_brick_kernel<JP, CL_, TI_, TO_>), bgrid, bblock, blds, s, v, cam, centers, valid, cubes, grids, gb, wgs, nby, nzc, zw)
         if ((io & 1) && JP == 16 && !((variant >> 9) & 1)) {
@@ -1876,6 +1927,23 @@ extern "C" int sp3d_unproject_fwd_strided(const float *const *hm_views, int hm_l
     if (rc) return rc;
     g.vec4 = ((g.dense || ((sY | sX | sJ | sB) & 3) == 0) && ((uintptr_t)cubes & 15) == 0) ? 1 : 0;
     return launch_nhwc(v, Jp, cam, centers, valid, cubes, nullptr, g, default_variant(g, false), false, io, (hipStream_t)stream);
+}
+
+extern "C" int sp3d_unproject_fwd_zdft(const float *const *hm_views, int Jp, const float *cam, const float *centers,
+                                       const uint8_t *valid, float *spec, int B, int V, int J, int h, int w, int X, int Y,
+                                       int Z, const float *grid_size, int W_in, int H_in, int SZ, void *stream)
+{
+    Geom g;
+    int rc = make_geom(g, B, V, J, h, w, X, Y, Z, grid_size, W_in, H_in);
+    if (rc) return rc;
+    if (!cam || !centers || !valid || !spec) return SP3D_ENULL;
+    if (Jp != 16 || Z != ZDZ || SZ != ZDSZ || (X % BR) || (Y % BR) || w < 2 || h < 2 || (int64_t)h * w > (1 << 24) ||
+        ((uintptr_t)spec & 127))
+        return SP3D_EUNSUPPORTED;
+    Views v;
+    rc = load_views(v, hm_views, V);
+    if (rc) return rc;
+    return launch_nhwc(v, Jp, cam, centers, valid, spec, nullptr, g, 56 | SP3D_VARIANT_ZD, false, 0, (hipStream_t)stream);
 }
 
 extern "C" int sp3d_unproject_fwd(const float *const *hm_views, int hm_layout, int Jp, const float *cam,

@@ -83,6 +83,17 @@ class CuboidProposalNet(nn.Module):
         # ... on this grid as channels-last 16-channel cubes (its z pass is a HIP kernel that reads them as they are),
         cl16 = direct and self.v2v_net.wants_channels_last_cubes(*self.cube_size)
         # ... otherwise straight into that conv's zero-padded planar input buffer
+        # ... or, round 6, not at all: the kernel keeps a 4 x 4 bundle of z columns in LDS and emits their z-spectrum, which
+        # is what the opening conv computes from the cubes first (sp3d_unproject_fwd_zdft; bit-identical, one launch and
+        # 2 x 32.8 MB of HBM traffic less at B = 4)
+        sz = self.v2v_net.wants_zspectrum(*self.cube_size, hms[0].shape[1]) if cl16 else None
+        if sz is not None and self.project_layer.io_dtype == torch.float32 and self.project_layer.jp_for(hms[0].shape[1]) == 16 \
+                and self.project_layer.mode in ("auto", "nhwc"):
+            from .v2v_net import TiledZSpectrum
+            spec = self.project_layer.get_voxel_zspectrum(hms, meta, self.grid_size, [self.grid_center], self.cube_size, sz,
+                                                          flip_xcoords=flip_xcoords)
+            root_cubes = self.v2v_net(TiledZSpectrum(spec, *self.cube_size, sz)).squeeze(1)
+            return root_cubes, self.proposal_layer(root_cubes, meta)
         out = self.v2v_net.input_view(hms[0].shape[0], *self.cube_size, hms[0].device) if direct and not cl16 else None
         cubes, _ = self.project_layer.get_voxel(hms, meta, self.grid_size, [self.grid_center], self.cube_size,
                                                 flip_xcoords=flip_xcoords, want_grids=False,

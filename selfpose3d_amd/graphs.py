@@ -26,7 +26,7 @@ class GraphedRootNet:
     def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3,
                  time_unprojection: bool = False):
         """``time_unprojection``: measurement only - the graph carries one-thread clock-stamp kernels around
-        ``ProjectLayer.get_voxel`` so that ``unprojection_us()`` reads the kernel's time INSIDE the replayed step (between
+        ``ProjectLayer.get_voxel`` / ``get_voxel_zspectrum`` so that ``unprojection_us()`` reads the kernel's time INSIDE the replayed step (between
         the camera fetch before it and the convolutions behind it), not that of a stand-alone launch."""
         self.net = net
         self._stamps = None
@@ -62,25 +62,27 @@ class GraphedRootNet:
                 lib.sp3d_debug_stamp.restype = C.c_int
                 lib.sp3d_debug_stamp.argtypes = [C.c_void_p, C.c_void_p]
                 self._stamps = torch.zeros(3, dtype=torch.int64, device=dev)
-                inner = pl.get_voxel
-
                 def stamp(i):
                     _lib.check(lib.sp3d_debug_stamp(self._stamps[i:].data_ptr(), _lib._stream(dev)), "sp3d_debug_stamp")
 
-                def timed_get_voxel(*a, **k):
-                    stamp(0)
-                    r = inner(*a, **k)
-                    stamp(1)
-                    stamp(2)
-                    return r
-                pl.get_voxel = timed_get_voxel          # instance attribute: shadows the method while capturing only
+                def timed(inner):
+                    def call(*a, **k):
+                        stamp(0)
+                        r = inner(*a, **k)
+                        stamp(1)
+                        stamp(2)
+                        return r
+                    return call
+                # instance attributes: shadow the methods while capturing only (get_voxel_zspectrum: the unprojection fused
+                # with the opening conv's z pass, what the root net calls on the root grid since round 6)
+                pl.get_voxel, pl.get_voxel_zspectrum = timed(pl.get_voxel), timed(pl.get_voxel_zspectrum)
             try:
                 with torch.cuda.graph(self.graph), torch.no_grad():
                     _lib.fetch_ring(self._ring, self.cam_dev, self._counter)
                     self.out = net(self.static_hms, meta, flip_xcoords)
             finally:
                 if time_unprojection:
-                    del pl.get_voxel
+                    del pl.get_voxel, pl.get_voxel_zspectrum
         # the captured kernels read the folded inference plan's tensors by address: keep them alive even if the net
         # drops its plan later (train() / load_state_dict / invalidate_plan)
         self._plan = getattr(getattr(net, "v2v_net", None), "_plan", None)

@@ -294,5 +294,32 @@ class ProjectLayer(nn.Module):
                                           bool(channels_last), sample_of, out, *heatmaps)
         return cubes, (grids if want_grids else None)
 
+    def get_voxel_zspectrum(self, heatmaps, meta, grid_size, grid_center, cube_size, SZ: int, flip_xcoords=None):
+        """Inference only, root grid only (round 6): ``get_voxel`` FUSED with the z pass of the V2V net's frequency-domain
+        opening conv - the cubes are never written.  Returns the (B, J, SZ//2+1, X/4, Y/4, 16) complex64 z-spectrum of the
+        cubes ``get_voxel`` would return (bit-identical to ``_lib.zdft_fwd_cl`` of its channels-last result), in the
+        4 x 4-tiled layout ``_lib.cfft2d_88_tiled`` reads.  Same reference semantics (project_layer.py:42-102)."""
+        if torch.is_grad_enabled() and any(h.requires_grad for h in heatmaps):
+            raise _lib.Sp3dError("get_voxel_zspectrum is an inference path (no autograd); use get_voxel")
+        device = heatmaps[0].device
+        if not heatmaps[0].is_cuda:
+            raise _lib.Sp3dError("ProjectLayer: heat-maps must be on the GPU (no CPU fallback)")
+        B, J, h, w = heatmaps[0].shape
+        if [w, h] != self.heatmap_size:
+            raise _lib.Sp3dError(f"heat-map tensor is {w}x{h} but cfg.NETWORK.HEATMAP_SIZE is {self.heatmap_size}")
+        if self.io_dtype != torch.float32 or self.jp_for(J) != 16 or self.mode not in ("auto", "nhwc") or w < 2 or h < 2:
+            raise _lib.Sp3dError("get_voxel_zspectrum: fp32 NHWC path with 13..16 joints only")
+        cam = self.camera_table(meta, B, flip_xcoords, device)
+        centers, valid = self.centers_valid(grid_center, B, device)
+        source = _packed_source(heatmaps, 16, torch.float32)
+        if source is not None:
+            packed = source.detach()
+        elif self.cache_packs:
+            packed = packed_heatmaps(heatmaps, 16, torch.float32)
+        else:
+            packed = _lib.pack_heatmaps([x.detach() for x in heatmaps], jp=16)
+        return _lib.unproject_fwd_zdft([packed[c] for c in range(len(heatmaps))], 16, cam, centers, valid, B, J, h, w,
+                                       [int(v) for v in cube_size], [float(v) for v in grid_size], self.img_size, int(SZ))
+
     def forward(self, heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=None):
         return self.get_voxel(heatmaps, meta, grid_size, grid_center, cube_size, flip_xcoords=flip_xcoords)

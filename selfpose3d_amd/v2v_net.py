@@ -197,6 +197,17 @@ class _EncDec(nn.Module):
         return x
 
 
+class TiledZSpectrum:
+    """What the fused root-grid unprojection hands to the opening conv INSTEAD of cubes (ProjectLayer.get_voxel_zspectrum):
+    the z-spectrum of the (B, cin, X, Y, Z) cubes, (B, cin, SZ//2+1, X/4, Y/4, 16) complex64 in 4 x 4 tiles.  Quacks like the
+    cubes where the plan looks (shape / device / dtype)."""
+
+    def __init__(self, spec: torch.Tensor, X: int, Y: int, Z: int, SZ: int):
+        self.spec, self.X, self.Y, self.Z, self.SZ = spec, int(X), int(Y), int(Z), int(SZ)
+        self.shape = (int(spec.shape[0]), int(spec.shape[1]), self.X, self.Y, self.Z)
+        self.device, self.is_cuda, self.dtype = spec.device, spec.is_cuda, torch.float32
+
+
 class _FoldedV2V:
     """Inference execution plan of a V2VNet: every BatchNorm3d (running statistics) is folded into the
     preceding (transposed) conv's weights, so a layer is one MIOpen conv (no bias) + ONE fused
@@ -362,6 +373,8 @@ class _FoldedV2V:
         w0, s0 = self.t["front"]
         cin = w0.shape[1]
         have = x.shape[1]
+        if isinstance(x, TiledZSpectrum):
+            return self._tail(self._front_zspectrum(x, w0, s0))
         if self.net.fft_front and w0.shape[2] == 7 and have >= cin:
             x = self._front_fft(x, w0, s0)
             return self._tail(x)
@@ -434,6 +447,35 @@ class _FoldedV2V:
         off = x.data_ptr() - buf.data_ptr()
         per = cin * vol * buf.element_size()
         return off >= 0 and off % per == 0 and off // per + x.shape[0] <= buf.shape[0]
+
+    def _weights_z(self, w0, S):
+        """the opening conv's weight spectrum with kz as the slowest frequency index (what the direct z-DFT form contracts with)"""
+        wkey, zkey = ("Wf", S), ("Wz", S)
+        if zkey not in self.t:
+            if wkey not in self.t:
+                k = int(w0.shape[2])
+                wp = torch.zeros(tuple(w0.shape[:2]) + S, dtype=torch.float32, device=w0.device)
+                wp[:, :, :k, :k, :k] = w0.float()
+                wp = torch.roll(wp, shifts=(-(k // 2),) * 3, dims=(2, 3, 4))
+                self.t[wkey] = (torch.conj(torch.fft.rfftn(wp, dim=(2, 3, 4))).resolve_conj() /
+                                float(S[0] * S[1] * S[2])).contiguous()
+            self.t[zkey] = self.t[wkey].permute(0, 1, 4, 2, 3).contiguous()
+            if not any(k[0] == "xpad" for k in self.t if isinstance(k, tuple)):
+                del self.t[wkey]                       # nobody asked for the planar buffer: keep one spectrum only
+        return self.t[zkey]
+
+    def _front_zspectrum(self, z: "TiledZSpectrum", w0, s0):
+        """opening conv when the unprojection already delivered the z-spectrum (round 6): x,y plane transforms (un-tiling
+        on load) -> contraction -> inverse x,y -> inverse z-DFT + shift + ReLU.  Same kernels and bits as the cubes path of
+        _front_fft minus zdft_fwd_cl_kernel (and minus the cubes' trip through HBM)."""
+        from . import _lib
+        k = int(w0.shape[2])
+        S = self._fft_shape(z.X, z.Y, z.Z, k)
+        if S[2] != z.SZ or S[0] != 88 or S[1] != 88 or int(w0.shape[1]) != z.shape[1] or int(w0.shape[0]) != 16:
+            raise _lib.Sp3dError(f"TiledZSpectrum of {z.shape} (SZ {z.SZ}) does not fit this net's opening conv (FFT shape {S})")
+        Xs = _lib.cfft2d_88_tiled(z.spec, z.X, z.Y)
+        Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self._weights_z(w0, S)), True, rows_out=z.X)
+        return _lib.zdft_inv_cl(Ys, z.X, z.Y, z.Z, S[2], s0, True)
 
     def _front_fft(self, x, w0, s0):
         """the 7x7x7 opening conv in the frequency domain: zero-padded rFFT (rocFFT via torch.fft) ->
@@ -582,6 +624,10 @@ class V2VNet(nn.Module):
         return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x):
+        if isinstance(x, TiledZSpectrum):
+            if self._plan is None:
+                self._plan = _FoldedV2V(self)
+            return self._plan.run(x)
         if self.fused_inference and not self.training and not torch.is_grad_enabled() and x.is_cuda \
                 and x.dtype == torch.float32 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[4] % 4 == 0:
             if self._plan is None:
@@ -631,6 +677,21 @@ class V2VNet(nn.Module):
         cl = w1.is_contiguous(memory_format=torch.channels_last_3d) and not w1.is_contiguous()
         return bool(w0.is_cuda and cl and (int(Z), int(S[2]), 16) in _lib.ZDFT_SHAPES and int(w0.shape[0]) == 16
                     and int(w0.shape[1]) <= 16)
+
+    def wants_zspectrum(self, X, Y, Z, cin: int):
+        """SZ when the next inference forward can start from the cubes' z-spectrum (``TiledZSpectrum``: the unprojection
+        fused with the opening conv's z pass, root grid), else None.  ``fuse_zdft`` (default on; SP3D_FUSE_ZDFT=0 turns it
+        off for A/B) and the conditions of the direct z-DFT form + 88 x 88 planes + a float32 inference plan."""
+        import os
+        if not getattr(self, "fuse_zdft", os.environ.get("SP3D_FUSE_ZDFT", "1") not in ("0", "")):
+            return None
+        if self.training or torch.is_grad_enabled() or not self.fused_inference or not self.wants_channels_last_cubes(X, Y, Z):
+            return None
+        w0 = self.front_layers[0].block[0].weight
+        S = _FoldedV2V._fft_shape(X, Y, Z, int(w0.shape[2]))
+        if S[0] != 88 or S[1] != 88 or X % 4 or Y % 4 or int(w0.shape[1]) != int(cin) or w0.dtype != torch.float32:
+            return None
+        return int(S[2])
 
     def wants_planar_input(self) -> bool:
         """True when the next forward will take the FFT opening conv: it reads plain (B,C,X,Y,Z) cubes with the real
