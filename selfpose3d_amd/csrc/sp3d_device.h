@@ -52,6 +52,11 @@ struct Geom {
     // brick decode: wg -> (z chunk, y brick, x brick)
     int bk_nxy, bk_nby;
     uint32_t bk_magic_nxy, bk_magic_nby;
+    // xm_mode 3 (round 6, brick kernels, B in {1, 2, 4}): the 8 / B XCDs of a sample each own ONE rectangular (x, y) block
+    // of brick columns over the whole z extent instead of round-robin chunks (set_block_fields): an XCD's L2 then sees the
+    // part of every view its block projects to, once (tools/sim_xcd_map.py: L2 fills 6.9x -> 2.6x the heat-maps at B = 1)
+    int blk_log2py, blk_w, blk_h, blk_nbx, blk_nzc;
+    uint32_t blk_magic_wh, blk_magic_h;
 };
 
 // torch.linspace(-L/2, L/2, n)[i] in fp32 (project_layer.py:28-30; ATen CPU kernel form)
@@ -405,6 +410,22 @@ inline void set_xcd_fields(Geom &g, int tiles)
         g.xm_log2xps = g.xm_log2K = 0; g.xm_rows = 0;
     }
 }
+// host: block map (xm_mode 3) for nbx x nby x nzc brick stacks per sample; returns the grid size in workgroups, or 0 when
+// the batch size has no whole number of XCDs per sample (the caller keeps the chunk map)
+inline int set_block_fields(Geom &g, int nbx, int nby, int nzc)
+{
+    if (!(g.B == 1 || g.B == 2 || g.B == 4)) return 0;
+    const int xps = 8 / g.B;
+    const int px = xps == 8 ? 2 : (xps == 4 ? 2 : 1), py = xps / px;       // 2 x 4, 2 x 2, 1 x 2 blocks
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    g.xm_mode = 3;
+    g.xm_log2xps = ilog2(xps);
+    g.blk_log2py = ilog2(py);
+    g.blk_w = (nbx + px - 1) / px; g.blk_h = (nby + py - 1) / py; g.blk_nbx = nbx; g.blk_nzc = nzc;
+    g.blk_magic_wh = (uint32_t)((0x100000000ull / (uint64_t)(g.blk_w * g.blk_h)) + 1ull);
+    g.blk_magic_h = (uint32_t)((0x100000000ull / (uint64_t)g.blk_h) + 1ull);
+    return 8 * nzc * g.blk_w * g.blk_h;
+}
 inline void set_brick_fields(Geom &g, int nxy, int nby)
 {
     g.bk_nxy = nxy; g.bk_nby = nby;
@@ -429,6 +450,17 @@ __device__ __forceinline__ bool xcd_map_fast(int bid, const Geom &g, int &b, int
         return tile < g.xm_tiles;
     }
     int q, r;
+    if (g.xm_mode == 3) {
+        b = x >> g.xm_log2xps;
+        const int sub = x & ((1 << g.xm_log2xps) - 1);
+        const int pxi = sub >> g.blk_log2py, pyi = sub & ((1 << g.blk_log2py) - 1);
+        int zc, t, lx, ly;
+        udiv_magic((uint32_t)slot, (uint32_t)(g.blk_w * g.blk_h), g.blk_magic_wh, zc, t);      // z slowest, then x, then y
+        udiv_magic((uint32_t)t, (uint32_t)g.blk_h, g.blk_magic_h, lx, ly);
+        const int bx = pxi * g.blk_w + lx, by = pyi * g.blk_h + ly;
+        tile = (zc * g.blk_nbx + bx) * g.bk_nby + by;
+        return zc < g.blk_nzc && bx < g.blk_nbx && by < g.bk_nby;
+    }
     if (g.xm_mode == 1) {
         udiv_magic((uint32_t)slot, (uint32_t)g.xm_tiles, g.xm_magic_tiles, q, r);
         b = x + 8 * q; tile = r;

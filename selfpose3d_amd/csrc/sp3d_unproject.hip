@@ -701,6 +701,7 @@ constexpr int BR = 4;
 // B = 4) and one launch from the root-net step; cfft2d_88_kernel un-tiles while it loads a plane into LDS.
 constexpr int ZDZ = 20, ZDSZ = 28;
 constexpr int SP3D_VARIANT_ZD = 1 << 24;        // launch_nhwc `variant` bit: brick stacks emit the z-spectrum
+constexpr int SP3D_VARIANT_BLOCKS = 1 << 25;    // launch_nhwc `variant` bit: block map of the bricks (Geom::xm_mode 3)
 template <int JP, bool OUTCL, typename TI = float, typename TO = float, bool ZD = false>
 __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
                                                                 const float *__restrict__ centers,
@@ -1551,6 +1552,7 @@ static int make_geom(Geom &g, int B, int V, int J, int h, int w, int X, int Y, i
     g.xcd_order = 0;
     g.xm_mode = 2; g.xm_log2xps = g.xm_log2K = g.xm_rows = 0; g.xm_tiles = 1; g.xm_magic_tiles = 0;
     g.bk_nxy = g.bk_nby = 1; g.bk_magic_nxy = g.bk_magic_nby = 0;
+    g.blk_log2py = 0; g.blk_w = g.blk_h = g.blk_nbx = g.blk_nzc = 1; g.blk_magic_wh = g.blk_magic_h = 0;
     g.N = (int)N; g.YZ = Y * Z; g.W_in = W_in; g.H_in = H_in;
     g.sB = (long long)J * N; g.sJ = (int)N; g.sX = Y * Z; g.sY = Z; g.dense = 1; g.vec4 = 1;
     g.Lx = grid_size[0]; g.Ly = grid_size[1]; g.Lz = grid_size[2];
@@ -1629,6 +1631,8 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         }
         set_xcd_fields(gb, wgs);
         set_brick_fields(gb, nbx * nby, nby);
+        // tuning bit 25: one rectangular block of brick columns per XCD instead of round-robin chunks (xm_mode 3)
+        const int block_grid = (variant & SP3D_VARIANT_BLOCKS) ? set_block_fields(gb, nbx, nby, nzc) : 0;
         constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
         size_t blds = (size_t)zw * WLDS * sizeof(float);
         // round-5 L1-residency experiment (measurement only): tuning bit 10 = view-synchronous workgroups (only when every
@@ -1645,7 +1649,7 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
                 if (ea != hipSuccess) return (int)ea;
             }
         }
-        dim3 bgrid(xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
+        dim3 bgrid(block_grid ? block_grid : xcd_grid_blocks(gb.B, wgs, gb.xcd_chunk)), bblock(64 * zw);
         if (variant & SP3D_VARIANT_ZD) {   // the stack's cubes leave as their z-spectrum (sp3d_unproject_fwd_zdft)
             if constexpr (JP == 16) {
                 if (io || out_cl || grids || g.Z != ZDZ || nzc != 1 || zw != ZDZ / BR || (g.X % BR) || (g.Y % BR) || g.pass_mask)
