@@ -701,7 +701,7 @@ constexpr int BR = 4;
 // B = 4) and one launch from the root-net step; cfft2d_88_kernel un-tiles while it loads a plane into LDS.
 constexpr int ZDZ = 20, ZDSZ = 28;
 constexpr int SP3D_VARIANT_ZD = 1 << 24;        // launch_nhwc `variant` bit: brick stacks emit the z-spectrum
-constexpr int SP3D_VARIANT_BLOCKS = 1 << 25;    // launch_nhwc `variant` bit: block map of the bricks (Geom::xm_mode 3)
+constexpr int SP3D_VARIANT_CHUNKS = 1 << 22;    // launch_nhwc `variant` bit: round-5 chunk map of the bricks instead of blocks / octants
 template <int JP, bool OUTCL, typename TI = float, typename TO = float, bool ZD = false>
 __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
                                                                 const float *__restrict__ centers,
@@ -1631,8 +1631,10 @@ static int launch_nhwc_jp(const Views &v, const float *cam, const float *centers
         }
         set_xcd_fields(gb, wgs);
         set_brick_fields(gb, nbx * nby, nby);
-        // tuning bit 25: one rectangular block of brick columns per XCD instead of round-robin chunks (xm_mode 3)
-        const int block_grid = (variant & SP3D_VARIANT_BLOCKS) ? set_block_fields(gb, nbx, nby, nzc) : 0;
+        // default since round 6 (B in {1, 2, 4}): one block of brick columns per XCD - octants at B = 1, quadrants at B = 2,
+        // halves at B = 4 - instead of round-robin chunks; same results, L2 fills 138 -> 60 MB on the 160x160x40 grid,
+        // 75 -> 56 MB on the root grid at B = 4 (profiles/r06_pmc_blocks.json).  Tuning bit 22 restores the chunk map.
+        const int block_grid = (variant & SP3D_VARIANT_CHUNKS) || (variant & 256) ? 0 : set_block_fields(gb, nbx, nby, nzc);
         constexpr int WLDS = (JP * WOSTR > WREC) ? JP * WOSTR : WREC;
         size_t blds = (size_t)zw * WLDS * sizeof(float);
         // round-5 L1-residency experiment (measurement only): tuning bit 10 = view-synchronous workgroups (only when every

@@ -114,3 +114,16 @@ report("8 x 1 (x slabs)", bxc * 8 // nbx, sweeps)
 # interleaved: 16 blocks (4 x 4), XCD x gets blocks x and 15 - x (a far and a near one: balances the work)
 blk = (bxc * 4 // nbx) * 4 + byc * 4 // nby
 report("4 x 4 blocks, XCD x = blocks {x, 15 - x}", np.where(blk < 8, blk, 15 - blk), sweeps)
+
+# ---- third table: octants (quadrants split along their diagonal): equal column counts, symmetric for ring rigs ---------
+cx, cy = nbx / 2, nby / 2
+u = np.where(bxc < cx, cx - 1 - bxc, bxc - cx).astype(int)        # distance from the centre lines, 0 .. nbx/2-1
+v = np.where(byc < cy, cy - 1 - byc, byc - cy).astype(int)
+quad = (bxc >= cx).astype(int) * 2 + (byc >= cy).astype(int)
+upper = (v < u) | ((v == u) & (u % 2 == 0))
+octant = quad * 2 + upper.astype(int)
+print(f"\n| assignment | sweep inside an XCD | L2 fills MB | x heat-maps | busiest XCD's work / mean |\n|---|---|---:|---:|---:|")
+report("8 octants (quadrants cut along the diagonal)", octant,
+       {"z slowest, rows outwards": bzc * 10000 + np.maximum(u, v) * 100 + np.minimum(u, v),
+        "rows outwards, z fastest": (np.maximum(u, v) * 100 + np.minimum(u, v)) * nbz + bzc})
+report("2 x 2 quadrants, two XCDs interleaved by column parity", quad * 2 + ((bxc + byc) & 1), {"z slowest": None})
