@@ -44,6 +44,9 @@ for name, B, V, cube, gs, fine in (("coarse_b2", 2, 5, syn.INITIAL_CUBE_SIZE, sy
                                                                                 cube, gs, img, sample_of=sample_of)), 1)
     res[name]["bwd_packed_deterministic_us"] = round(timed(lambda: _lib.unproject_bwd_packed(
         cam, centers, valid, g, mask, B, V, J, 16, h, w, cube, gs, img, sample_of=sample_of, deterministic=True)), 1)
+    for nm, sc in (("per_tap", _lib.SCATTER_PER_TAP), ("merge", _lib.SCATTER_MERGE)):      # round 6: both kernels on every grid
+        res[name][f"bwd_packed_{nm}_us"] = round(timed(lambda: _lib.unproject_bwd_packed(
+            cam, centers, valid, g, mask, B, V, J, 16, h, w, cube, gs, img, sample_of=sample_of, scatter=sc)), 1)
     res[name]["fwd_train_us"] = round(timed(lambda: _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam,
                                                                         centers, valid, P, J, h, w, cube, gs, img, False,
                                                                         sample_of=sample_of, pass_mask=mask)), 1)
