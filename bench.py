@@ -247,26 +247,49 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
 
     with torch.no_grad():
         step_cl = bool(getattr(model.v2v_net, "wants_channels_last_cubes", lambda *a: False)(*cube))
+        # round 6: on this grid the step runs the unprojection FUSED with the opening conv's z pass (no cubes in HBM at all)
+        sz = getattr(model.v2v_net, "wants_zspectrum", lambda *a: None)(*cube, J) if step_cl else None
+    step_zd = sz is not None
+
+    def k_fused():                # the launch of the step: heat-maps in, 4x4-tiled z-spectrum of the cubes out
+        _lib.unproject_fwd_zdft(views, 16, cam, centers, valid, B, J, h, w, cube, gs, img, sz)
+
     t_lin = event_time_ms(k_lin_planar, iters, dev)
     t_brick = event_time_ms(k_brick_cl, iters, dev)
-    t_k = t_brick if step_cl else t_lin
+    t_fused = t_zdft = None
+    if step_zd:
+        t_fused = event_time_ms(k_fused, iters, dev)
+        cubes_cl = _lib.unproject_fwd(views, _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16, h, w, cube, gs, img, False,
+                                      channels_last=True)[0]
+        S = (88, 88, int(sz))
+        t_zdft = event_time_ms(lambda: _lib.zdft_fwd_cl(cubes_cl, J, S), iters, dev)
+        del cubes_cl
+    t_k = t_fused if step_zd else (t_brick if step_cl else t_lin)
     t_planar = event_time_ms(k_planar, max(10, iters // 10), dev)
     t_pack = event_time_ms(k_pack, iters, dev)
     with torch.no_grad():
         t_strided = event_time_ms(k_strided, iters, dev) if fft_view is not None else None
     # algorithmic bytes per launch: read every heat-map element once, write cubes
     # once; `grids` is not requested by the root net so its 3N term is dropped.
-    alg_bytes = 4.0 * B * (V * J * h * w + J * N)
+    alg_bytes_8d = 4.0 * B * (V * J * h * w + J * N)
+    # the fused launch's own algorithmic bytes: every heat-map element read once + its OUTPUT written
+    # once - the z-spectrum, (SZ/2+1) complex bins per Z-real column and channel: 8*B*J*K*X*Y bytes instead of 4*B*J*N
+    alg_bytes = (4.0 * B * V * J * h * w + 8.0 * B * J * (sz // 2 + 1) * cube[0] * cube[1]) if step_zd else alg_bytes_8d
     achieved = alg_bytes / (t_k * 1e-3) / 1e9
     path = t_k + (t_pack if planar_input else 0.0)
     out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "sp3d::unproject_brick_kernel<16,true,float,float>" if step_cl
-                  else "sp3d::unproject_pipe_kernel<16,true,1,false,float,float>", "kernel_us": round(t_k * 1e3, 2),
-        "kernel_result": "channels-last (B,80,80,20,16) cubes read by the opening conv's z-DFT pass" if step_cl
-                         else "planar (B,15,80,80,20) cubes",
+        "kernel": ("sp3d::unproject_brick_kernel<16,false,float,float,true> (unprojection + z-DFT of the opening conv)" if step_zd else
+                   "sp3d::unproject_brick_kernel<16,true,float,float>" if step_cl
+                   else "sp3d::unproject_pipe_kernel<16,true,1,false,float,float>"), "kernel_us": round(t_k * 1e3, 2),
+        "kernel_result": ("(B,15,15,20,20,16) complex z-spectrum of the cubes in 4x4 tiles, read by the opening conv's x,y pass; "
+                          "the cubes themselves never reach HBM") if step_zd else
+                         ("channels-last (B,80,80,20,16) cubes read by the opening conv's z-DFT pass" if step_cl
+                          else "planar (B,15,80,80,20) cubes"),
         "algorithmic_bytes": int(alg_bytes),
+        "algorithmic_bytes_what": ("fused launch: heat-maps once (4*B*V*J*h*w) + z-spectrum once (8*B*J*15*X*Y)" if step_zd else
+                                   "SURVEY 8(d): heat-maps once + cubes once"),
         "path_us": round(path * 1e3, 2),
         "path": "unprojection kernel only: the heat-maps arrive as views of the backbone's channels-last buffer"
                 if not planar_input else "re-tiling pass (pack_nhwc_kernel<16>) + unprojection kernel: planar hand-over",
@@ -280,8 +303,23 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
                              "unproject_planar_kernel<16>": round(t_planar * 1e3, 2)},
         "timing": f"HIP events on the launch stream, {iters} back-to-back launches, inputs L2/MALL-warm",
     }
+    if step_zd:
+        two = t_brick + t_zdft
+        out["unprojection_only"] = {
+            "what": "SURVEY 8(d)'s accounting (heat-maps once + cubes once) for continuity with rounds 1-5: the un-fused kernel "
+                    "(SP3D_FUSE_ZDFT=0 runs it in the step), and the fused launch charged with the same bytes",
+            "algorithmic_bytes": int(alg_bytes_8d),
+            "unfused_kernel": "sp3d::unproject_brick_kernel<16,true,float,float>", "unfused_kernel_us": round(t_brick * 1e3, 2),
+            "unfused_frac": round(alg_bytes_8d / (t_brick * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fused_frac_on_these_bytes": round(alg_bytes_8d / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["fusion"] = {"replaces_us": {"unproject_brick_kernel<16,true>": round(t_brick * 1e3, 2),
+                                         "zdft_fwd_cl_kernel<20,28,16>": round(t_zdft * 1e3, 2), "sum": round(two * 1e3, 2)},
+                         "fused_us": round(t_k * 1e3, 2),
+                         "bytes_the_two_kernels_move": int(alg_bytes_8d + 4.0 * B * 16 * N + 8.0 * B * J * (sz // 2 + 1) * 88 * 88),
+                         "what": "stand-alone, warm; in the step: roofline.in_step_graph_stamps (fused) vs profiles/r05_bench_kernel_stats_final.md "
+                                 "(34.2 + 22.4 us)"}
     # PMC record of the kernel the step runs (tools/profile_round.sh): the brick kernel's or the planar-result kernel's
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json" if step_cl else "pmc_traffic_planar.json")
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic_fused.json" if step_zd else ("pmc_traffic.json" if step_cl else "pmc_traffic_planar.json"))
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
@@ -296,7 +334,7 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
     # per iteration (the rocprofv3 in-graph average of the same kernel is in profiles/, see frac_in_step_source)
     if cold:
         thrash = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
-        run_k = k_brick_cl if step_cl else k_lin_planar
+        run_k = k_fused if step_zd else (k_brick_cl if step_cl else k_lin_planar)
         n_cc = max(20, iters // 6)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_cc)]
         for _ in range(3):
@@ -331,6 +369,9 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
         def k_cold():
             p = sets[state["i"] % nset]
             state["i"] += 1
+            if step_zd:
+                _lib.unproject_fwd_zdft([p[c] for c in range(V)], 16, cam, centers, valid, B, J, h, w, cube, gs, img, sz)
+                return
             _lib.unproject_fwd([p[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, 16 if step_cl else J,
                                h, w, cube, gs, img, False, channels_last=step_cl)
         t_cold = event_time_ms(k_cold, iters, dev)

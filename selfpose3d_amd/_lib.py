@@ -882,20 +882,20 @@ class _RenderJoints(torch.autograd.Function):
         check(lib.sp3d_render_joints_fwd(k.data_ptr(), cnt.data_ptr() if cnt is not None else None, N, Pn, J, h, w,
                                          float(sigma), out.data_ptr(), _stream(kps.device)), "sp3d_render_joints_fwd")
         ctx.save_for_backward(k, cnt if cnt is not None else torch.empty(0, device=kps.device))
-        ctx.geom = (h, w, float(sigma), cnt is not None)
-        return out
+        ctx.geom = (h, w, float(sigma), cnt is not None, kps.dtype)
+        return out if kps.dtype == torch.float32 else out.to(kps.dtype)      # float64 callers: fp32 kernel, caller's type
 
     @staticmethod
     def backward(ctx, gout):
         lib = load()
         k, cnt = ctx.saved_tensors
-        h, w, sigma, has_cnt = ctx.geom
+        h, w, sigma, has_cnt, in_dtype = ctx.geom
         N, Pn, J = (int(v) for v in k.shape[:3])
         g = gout.contiguous().float()
         gk = torch.empty_like(k)
         check(lib.sp3d_render_joints_bwd(k.data_ptr(), cnt.data_ptr() if has_cnt else None, g.data_ptr(), N, Pn, J, h, w,
                                          sigma, gk.data_ptr(), _stream(k.device)), "sp3d_render_joints_bwd")
-        return gk, None, None, None, None
+        return gk.to(in_dtype), None, None, None, None
 
 
 def render_joint_heatmaps(kps: torch.Tensor, count: Optional[torch.Tensor], h: int, w: int, sigma: float = 3.0):

@@ -120,6 +120,12 @@ class _UnprojectFn(torch.autograd.Function):
             ctx.packed_bwd = None
             cubes, grids = _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube_size,
                                               grid_size, layer.img_size, want_grids, sample_of=sample_of)
+        # float64 callers (the mixed-precision pins of tests/test_gpu_reference_pins_r3.py: a float64 model around THIS fp32
+        # path): the kernels compute and store fp32, the results travel on in the caller's type
+        ctx.wide = heatmaps[0].dtype == torch.float64
+        if ctx.wide:
+            cubes = cubes.double()
+            grids = grids.double() if grids is not None else None
         ctx.layer = layer
         ctx.geom = (tuple(grid_size), tuple(cube_size))
         ctx.sample_of = sample_of
@@ -136,15 +142,20 @@ class _UnprojectFn(torch.autograd.Function):
     def backward(ctx, grad_cubes, _grad_grids):
         cam, centers, valid, *hms = ctx.saved_tensors
         grid_size, cube_size = ctx.geom
+        if ctx.wide:
+            grad_cubes = grad_cubes.float()
+            wide = lambda gs: tuple(x.double() for x in gs)
+        else:
+            wide = tuple
         if ctx.packed_bwd is not None:
             mask, jp, batch, nv, J, h, w = ctx.packed_bwd
             grads = _lib.unproject_bwd_packed(cam, centers, valid, grad_cubes, mask, batch, nv, J, jp, h, w, cube_size,
                                               grid_size, ctx.layer.img_size, sample_of=ctx.sample_of,
                                               deterministic=ctx.layer.deterministic_backward)
-            return (None,) * 12 + tuple(grads)
+            return (None,) * 12 + wide(grads)
         grads = _lib.unproject_bwd(hms, cam, centers, valid, grad_cubes, cube_size, grid_size, ctx.layer.img_size,
                                    sample_of=ctx.sample_of)
-        return (None,) * 12 + tuple(grads)
+        return (None,) * 12 + wide(grads)
 
 
 class ProjectLayer(nn.Module):

@@ -21,6 +21,8 @@ def project_joints(joints: torch.Tensor, cam: torch.Tensor, stride: float = 4.0,
     ``trans`` (B,2,3): one crop affine for all views of a sample (the reference passes ``meta[0]['trans']``);
     default: the per-view affine of the table."""
     B, V = cam.shape[:2]
+    if joints.dtype == torch.float64:            # float64 callers (mixed-precision pins): the projection follows the poses' type
+        cam = cam.double()
     R = cam[..., CAM_R:CAM_R + 9].reshape(B, V, 1, 1, 3, 3)
     T = cam[..., CAM_T:CAM_T + 3].reshape(B, V, 1, 1, 3)
     f = cam[..., CAM_F:CAM_F + 2].reshape(B, V, 1, 1, 2)
@@ -49,5 +51,5 @@ def reprojection_heatmaps(joints: torch.Tensor, count: Optional[torch.Tensor], c
     kps = project_joints(joints, cam, stride, trans)                         # (V,B,P,J,2)
     V, B, P, J = kps.shape[:4]
     cnt = None if count is None else count.to(torch.int32).reshape(1, B).expand(V, B).reshape(-1)
-    hm = _lib.render_joint_heatmaps(kps.reshape(V * B, P, J, 2), cnt, h, w, sigma)
+    hm = _lib.render_joint_heatmaps(kps.reshape(V * B, P, J, 2), cnt, h, w, sigma)      # fp32 kernels, result in kps' type
     return hm.view(V, B, J, h, w)

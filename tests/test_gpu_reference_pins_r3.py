@@ -145,7 +145,18 @@ def _child(args, tmp_path):
     return rec
 
 
-def _train_step_child(tag, deterministic, batched=True):
+def _wide(x):
+    """every floating tensor of a (nested) batch structure -> float64"""
+    if torch.is_tensor(x):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, dict):
+        return {k: _wide(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_wide(v) for v in x)
+    return x
+
+
+def _train_step_child(tag, deterministic, batched=True, f64=False):
     """losses and gradients of one supervised train step against the reference's fp32 and float64 runs -> dict
     (batched: 0 = per-camera loop, 1 = one NCHW pass, 2 = one channels_last pass through the grouped BatchNorm kernels - the
     form tools/train_3d.py and the bench's train leg run)"""
@@ -166,6 +177,9 @@ def _train_step_child(tag, deterministic, batched=True):
     for pl in (model.root_net.project_layer, model.pose_net.project_layer):
         pl.deterministic_backward = deterministic
     inputs, t2d, w2d, t3d, meta, _ = gio.train_batch(cfg, B=2, seed=int(g["data_seed"]))
+    if f64:            # a float64 model around the fp32 HIP unprojection: the library's convolution kernels drop out of the error
+        model.double()
+        inputs, t2d, w2d, t3d = _wide(inputs), _wide(t2d), _wide(w2d), _wide(t3d)
     inputs = [x.to(dev) for x in inputs]
     pred, hms, gc, l2d, l3d, lcord = model(views=inputs, meta=meta, targets_2d=t2d, weights_2d=w2d, targets_3d=t3d[0])
     rec = {"hm_sum_rel": float(np.abs(np.array([float(h.double().sum()) for h in hms]) / g[f"{tag}_hm_sum"] - 1.0).max())}
@@ -250,7 +264,7 @@ def test_supervised_train_step_vs_reference(dev, tag, views, deterministic, tmp_
         assert rec["pose_out_grad_absmax"] == 0.0           # pose net not reached: zero-anchored, exactly zero gradient
 
 
-def _ssv_step_child(batched=True):
+def _ssv_step_child(batched=True, f64=False):
     from selfpose3d_amd.models import get_multi_person_pose_net
     from selfpose3d_amd import pose_resnet
     pose_resnet.PoseResNet.batch_views_in_training = bool(batched)
@@ -264,6 +278,9 @@ def _ssv_step_child(batched=True):
     model.to(dev).train()
     model.root_net.eval()                                # engine.train_3d_ssv / lib/core/function.py:46-48
     b = gio.train_batch(cfg, B=2, seed=int(g["data_seed"]), ssv=True)
+    if f64:
+        model.double()
+        b = _wide(b)
     (in1, t1, w1, d1, m1, _, in2, t2, w2, d2, m2, _, in3, t3, w3, d3, m3, _) = b
     in1, in2, in3 = ([x.to(dev) for x in v] for v in (in1, in2, in3))
     pred, hm3, gc, losses = model(views1=in1, meta1=m1, targets_2d1=t1, weights_2d1=w1, targets_3d1=d1[0],
@@ -317,6 +334,41 @@ def test_ssv_train_step_vs_reference(dev, views, tmp_path):
         assert v["err_vs_f64"] <= bound, (nm, v, bound, rec.get("library"))
 
 
+# Round 6 (advisor: the fp32 bounds above cannot see a gradient term that is a few percent off): the SAME steps with the model
+# in float64 - convolutions, BatchNorm (grouped kernels: float64 statistics), soft-argmax, losses - around the fp32 HIP
+# unprojection (forward, pass mask, scatter) and the fp32 rendering kernels.  The library's convolution choice no longer matters;
+# what is left is the fp32 rounding of this repo's own kernels, amplified by the step's conditioning (the reference's all-fp32
+# run is 1.4e-2 from its float64 run on the 3-D term).  Measured (profiles/r06_training_pins_f64.json; batched and looped backbone
+# passes agree to 5 digits - nothing library-dependent is left): supervised 3.7e-8 (2-D term), 1.37e-3 (3-D term), 1.19e-3 (first
+# root-V2V layer), 1.77e-3 / 2.2e-3 (pose terms, ground-truth proposals); SSV 9.6e-4 / 3.0e-4 / 5.6e-5; losses <= 3.4e-6.
+# One bound for all: 5e-3 - a gradient term that is 1 % off fails, where the fp32 bounds above stop at 4-8 %.
+F64_BOUND = 5e-3
+
+
+@pytest.mark.parametrize("tag,views", [("net", "batched_cl"), ("gt", "batched_cl"), ("net", "loop")])
+def test_supervised_train_step_float64_model_vs_reference_float64(dev, tag, views, tmp_path):
+    rec = _child(["--train-step-child", tag, 1, {"loop": 0, "batched": 1, "batched_cl": 2}[views], "f64"], tmp_path)
+    print(json.dumps(rec))
+    assert rec["valid_equal"]
+    for name in ("loss_2d", "loss_3d", "loss_cord"):
+        assert rec[name + "_rel"] <= 1e-5, (name, rec)
+    seen = 0
+    for key, v in rec.items():
+        if isinstance(v, dict) and "err_vs_f64" in v:
+            assert v["err_vs_f64"] <= F64_BOUND, (key, v)
+            seen += 1
+    assert seen >= 3
+
+
+@pytest.mark.parametrize("views", ["batched", "loop"])
+def test_ssv_train_step_float64_model_vs_reference_float64(dev, views, tmp_path):
+    rec = _child(["--ssv-step-child", int(views == "batched"), "f64"], tmp_path)
+    print(json.dumps(rec))
+    assert rec["keys_equal"] and rec["valid_equal"]
+    for nm in ("grad_final", "grad_pose_out", "grad_attn_final"):
+        assert rec[nm]["err_vs_f64"] <= F64_BOUND, (nm, rec[nm])
+
+
 @pytest.mark.miopen_sensitive
 def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
     """drop-in check: tools/train_3d.py dispatches MODEL multi_person_posenet_ssv / WITH_SSV to the
@@ -332,6 +384,7 @@ def test_train_entry_point_runs_an_ssv_yaml(dev, tmp_path):
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     if sys.argv[1] == "--train-step-child":
-        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])), int(sys.argv[4]))))
+        print(json.dumps(_train_step_child(sys.argv[2], bool(int(sys.argv[3])), int(sys.argv[4]),
+                                           len(sys.argv) > 5 and sys.argv[5] == "f64")))
     elif sys.argv[1] == "--ssv-step-child":
-        print(json.dumps(_ssv_step_child(bool(int(sys.argv[2])))))
+        print(json.dumps(_ssv_step_child(bool(int(sys.argv[2])), len(sys.argv) > 3 and sys.argv[3] == "f64")))

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=1, help="number of distinct input sets cycled through")
     ap.add_argument("--planar", action="store_true")
     ap.add_argument("--cl", action="store_true", help="channels-last result (16 channels)")
+    ap.add_argument("--zdft", action="store_true", help="root grid only: the unprojection fused with the opening conv's z pass")
     ap.add_argument("--bf16", action="store_true", help="bf16 heat-maps and cubes (configs[4]: unproject_brick_h_kernel)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -54,7 +55,9 @@ def main():
     torch.cuda.synchronize()
     for it in range(args.iters):
         hms, packed = sets[it % args.rotate]
-        if args.planar:
+        if args.zdft:
+            _lib.unproject_fwd_zdft([packed[c] for c in range(V)], 16, cam, centers, valid, B, J, h, w, cube, gs, img, 28)
+        elif args.planar:
             _lib.unproject_fwd(hms, _lib.LAYOUT_PLANAR, 0, cam, centers, valid, B, J, h, w, cube, gs, img, False)
         else:
             _lib.unproject_fwd([packed[c] for c in range(V)], _lib.LAYOUT_NHWC, 16, cam, centers, valid, B, J, h, w,
