@@ -143,6 +143,38 @@ def train_3d(config, model, optimizer, loader, epoch, output_dir=None, writer_di
             "batch_time": bt.avg}
 
 
+class ScalarLog:
+    """``add_scalar`` sink used when neither tensorboardX (what the reference imports, tools/train_3d.py:32) nor
+    torch.utils.tensorboard is importable: one JSON line per scalar in <log_dir>/scalars.jsonl"""
+
+    def __init__(self, log_dir):
+        import os
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self._f = open(self.path, "a")
+
+    def add_scalar(self, tag, value, global_step=None):
+        import json
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": None if global_step is None else int(global_step)}) + "\n")
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+def make_writer_dict(log_dir):
+    """the reference's writer_dict (tools/train_3d.py:183-187): a SummaryWriter when a TensorBoard package is present,
+    else ScalarLog; same scalar names either way (lib/core/function.py:155-174,329-334)"""
+    writer = None
+    for mod in ("tensorboardX", "torch.utils.tensorboard"):
+        try:
+            writer = __import__(mod, fromlist=["SummaryWriter"]).SummaryWriter(log_dir=log_dir)
+            break
+        except Exception:
+            continue
+    return {"writer": writer if writer is not None else ScalarLog(log_dir), "train_global_steps": 0, "valid_global_steps": 0}
+
+
 SSV_LOSS_KEYS = ("loss_2d", "loss_root_reg", "loss_root_syn", "loss_pose3d_ssv", "loss_attn_ssv", "loss_pose3d_l1_ssv")
 
 
@@ -198,6 +230,14 @@ def train_3d_ssv(config, model, optimizer, loader, epoch, output_dir=None, write
             logger.info(f"Epoch: [{epoch}][{i}/{len(loader)}]\tTime: {bt.val:.3f}s ({bt.avg:.3f}s)\t"
                         f"Speed: {V * B / max(bt.val, 1e-9):.1f} samples/s\tData: {dt.val:.3f}s\t" +
                         "\t".join(f"{k}: {m.val:.6f} ({m.avg:.6f})" for k, m in meters.items()))
+            if writer_dict and writer_dict.get("writer") is not None:            # function.py:155-174
+                w, g = writer_dict["writer"], writer_dict["train_global_steps"]
+                w.add_scalar("train_loss_2d", meters["loss_2d"].val, g)
+                w.add_scalar("train_loss_root", meters["loss_root_syn"].val + meters["loss_root_reg"].val, g)
+                w.add_scalar("train_loss_pose3d_ssv", meters["loss_pose3d_ssv"].val, g)
+                w.add_scalar("train_loss_attn_ssv", meters["loss_attn_ssv"].val, g)
+                w.add_scalar("train_loss", meters["losses"].val, g)
+                writer_dict["train_global_steps"] = g + 1
     out = {k: m.avg for k, m in meters.items()}
     out["batch_time"] = bt.avg
     return out

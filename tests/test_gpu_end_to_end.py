@@ -58,6 +58,54 @@ def test_cli_entry_points(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "root recall" in r.stderr
+    # scalars under the reference's names (lib/core/function.py:329-334), through tensorboardX / torch's writer when present,
+    # else selfpose3d_amd.engine.ScalarLog
+    logs = os.listdir(os.path.join(out, "log"))
+    assert logs, "no scalar log written"
+    if "scalars.jsonl" in logs:
+        import json
+        tags = {json.loads(ln)["tag"] for ln in open(os.path.join(out, "log", "scalars.jsonl"))}
+        assert {"train_loss", "train_loss_3d", "train_loss_cord"} <= tags
+    # validate without a checkpoint: an error as in the reference (tools/validate_3d.py:91-92), unless --random-init is given
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_3d.py"), "--cfg", CFG, "--frames", "2",
+                        "--test-file", os.path.join(out, "no_such_file.pth.tar")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "Check the model file for testing" in r.stderr
+
+
+def test_stage_handoff_through_the_cli(tmp_path):
+    """root-net stage run -> its model_epoch_1.pth.tar named by INIT_ROOTNET (and the same file, a whole-model file, by
+    PRETRAINED_BACKBONE + PRETRAINED_BACKBONE_PSEUDOGT) in the next stage's YAML -> tools/train_3d.py loads both and says so;
+    a YAML that names a missing file fails before training (reference tools/train_3d.py:150-180)"""
+    import yaml
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = yaml.safe_load(open(CFG))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_3d.py"), "--cfg", CFG, "--frames", "2",
+                        "--max-iters", "1"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = os.path.join(str(tmp_path), "output", "synthetic", "multi_person_posenet", "synthetic_small")
+    stage1 = os.path.join(out, "model_epoch_1.pth.tar")
+    assert os.path.isfile(stage1)
+    nxt = dict(base)
+    nxt["NETWORK"] = dict(base["NETWORK"], INIT_ROOTNET=stage1, PRETRAINED_BACKBONE=stage1, PRETRAINED_BACKBONE_PSEUDOGT=True,
+                          FREEZE_ROOTNET=True)
+    y2 = os.path.join(str(tmp_path), "stage2.yaml")
+    yaml.safe_dump(nxt, open(y2, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_3d.py"), "--cfg", y2, "--frames", "2",
+                        "--max-iters", "1"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "initialised from NETWORK.PRETRAINED_BACKBONE" in r.stderr and "initialised from NETWORK.INIT_ROOTNET" in r.stderr
+    sd1 = torch.load(stage1, map_location="cpu")
+    sd2 = torch.load(os.path.join(str(tmp_path), "output", "synthetic", "multi_person_posenet", "stage2", "final_state.pth.tar"),
+                     map_location="cpu")
+    root = [k for k in sd1 if k.startswith("root_net.") and sd1[k].is_floating_point() and "running" not in k]
+    assert root and all(torch.equal(sd1[k], sd2[k]) for k in root)          # loaded AND frozen: untouched by the step
+    nxt["NETWORK"]["INIT_ROOTNET"] = os.path.join(str(tmp_path), "missing.pth.tar")
+    y3 = os.path.join(str(tmp_path), "stage3.yaml")
+    yaml.safe_dump(nxt, open(y3, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_3d.py"), "--cfg", y3, "--frames", "2",
+                        "--max-iters", "1"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "missing.pth.tar" in r.stderr
 
 
 def test_rootnet_soft_forward_and_synthetic_training_branch():

@@ -627,3 +627,30 @@ def test_batched_camera_pack_equals_the_per_view_form_bit_for_bit(B, V):
         if i % 2:
             m["camera"]["R"] = m["camera"]["R"].numpy()
     assert pack_cameras(meta, B, img).tobytes() == _pack_cameras_per_view(meta, B, img).tobytes()
+
+
+def test_build_survives_an_unrepairable_packed_form_and_has_a_plain_hipcc_path(tmp_path, monkeypatch):
+    """round-5 advice: the assembly rewrite must not be able to fail the build.  (a) the rewrite refuses an instruction ->
+    that source is recompiled without packed-fp32 instructions (a warning, an object, nothing risky inside); (b)
+    SP3D_PLAIN_HIPCC=1 -> one plain `hipcc -c` per source, no packed-fp32 instructions, no hand-rolled bundling steps"""
+    from selfpose3d_amd import build, pk_src1
+    src = "sp3d_fftconv.hip"                                    # the smallest source: seconds to compile
+    cflags = [f for f in build.FLAGS if f != "-shared"]
+    real, calls = pk_src1.fix_asm, {"n": 0}
+
+    def refuse_once(text):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise ValueError("both multiplicands take their low result from a high half (simulated)")
+        assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text
+        return real(text)
+    monkeypatch.setattr(pk_src1, "fix_asm", refuse_once)
+    with pytest.warns(UserWarning, match="without packed-fp32"):
+        obj = build._compile_one(src, str(tmp_path), cflags, False)
+    assert calls["n"] == 2 and os.path.getsize(obj) > 1000
+    monkeypatch.setattr(pk_src1, "fix_asm", real)
+    monkeypatch.setenv("SP3D_PLAIN_HIPCC", "1")
+    plain = tmp_path / "plain"
+    plain.mkdir()
+    obj2 = build._compile_one(src, str(plain), cflags, False)
+    assert os.path.getsize(obj2) > 1000 and sorted(os.listdir(plain)) == [os.path.basename(obj2)]      # no intermediate files

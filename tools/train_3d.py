@@ -18,7 +18,7 @@ import torch
 
 from _common import init_from_config, load_checkpoint, make_loader, save_checkpoint, setup
 from selfpose3d_amd import distributed as D
-from selfpose3d_amd.engine import train_3d, train_3d_ssv, validate_3d
+from selfpose3d_amd.engine import make_writer_dict, train_3d, train_3d_ssv, validate_3d
 from selfpose3d_amd.models import get_multi_person_pose_net, is_ssv
 
 logger = logging.getLogger("train_3d")
@@ -66,11 +66,13 @@ def main():
     ddp = D.wrap_ddp(model, device, find_unused=D.needs_find_unused(cfg))
     sched = torch.optim.lr_scheduler.MultiStepLR(optimizer, list(cfg.TRAIN.LR_STEP), float(cfg.TRAIN.LR_FACTOR),
                                                  last_epoch=last)
+    # scalars as the reference logs them (train_loss_* per PRINT_FREQ iterations), rank 0 only
+    writer_dict = make_writer_dict(os.path.join(out, str(cfg.LOG_DIR))) if rank == 0 else None
     for epoch in range(start, int(cfg.TRAIN.END_EPOCH)):
         if hasattr(train_loader.sampler, "set_epoch"):
             train_loader.sampler.set_epoch(epoch)
         loop = train_3d_ssv if ssv else train_3d                       # reference tools/train_3d.py:167-170
-        stats = loop(cfg, ddp, optimizer, train_loader, epoch, out, None, device, args.max_iters)
+        stats = loop(cfg, ddp, optimizer, train_loader, epoch, out, writer_dict, device, args.max_iters)
         sched.step()
         prec = None if cfg.NETWORK.TRAIN_ONLY_2D else validate_3d(cfg, ddp, test_loader, epoch, out, with_ssv=ssv,
                                                                   device=device, max_iters=args.max_iters)
