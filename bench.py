@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--v2v-layout", choices=["ncdhw", "cl3d"], default="cl3d",
                     help="memory format of the V2V stack (fp32 either way)")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one HIP graph")
+    ap.add_argument("--graph-copies", type=int, default=int(os.environ.get("SP3D_GRAPH_COPIES", "1")),
+                    help="graph executables of the step replayed in turn (1: one executable, replays cannot overlap their launch)")
     ap.add_argument("--no-cold", action="store_true", help="skip timing the kernel on inputs rotating through >256 MiB")
     ap.add_argument("--planar-input", action="store_true",
                     help="hand the heat-maps over as the reference does, planar (B,J,h,w): adds the re-tiling pass to the step")
@@ -937,7 +939,7 @@ def main():
                 eager_step()                       # MIOpen algorithm search must happen outside capture
             torch.cuda.synchronize(dev)
             from selfpose3d_amd.graphs import GraphedRootNet
-            graphed = GraphedRootNet(model, hms, meta)
+            graphed = GraphedRootNet(model, hms, meta, copies=args.graph_copies)
             step, mode = (lambda: graphed()), "hipgraph"
         except Exception as e:                     # capture not possible: stay on the eager HIP path
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -992,7 +994,8 @@ def main():
                                           "shapes: shortens warm-ups, same kernels as a fresh search)" if miopen_db else
                                           "the process's own (MIOPEN_USER_DB_PATH / default)"),
                        "weights": "deterministic N(0,0.05) fill (tests/golden/rootnet_full.npz)",
-                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode},
+                       "v2v_layout": args.v2v_layout, "front_conv": args.front_conv, "winograd": not args.no_winograd, "launch": mode,
+                       "graph_executables": (args.graph_copies if mode == "hipgraph" else 0)},
             "views_x_frames_per_s": round(value * V, 3),
             "value_window": (f"first of {len(spread)} windows of {args.steps} steps; by ms_per_step it ranks "
                              f"{1 + sorted(spread).index(spread[0])} of {len(spread)} (1 = fastest): legs measured later in the run may read "

@@ -24,7 +24,7 @@ class GraphedRootNet:
     BLOCKING_EVENTS = False
 
     def __init__(self, net, heatmaps: Sequence[torch.Tensor], meta: Sequence[dict], flip_xcoords=None, warmup: int = 3,
-                 time_unprojection: bool = False):
+                 time_unprojection: bool = False, copies: int = 1):
         """``time_unprojection``: measurement only - the graph carries one-thread clock-stamp kernels around
         ``ProjectLayer.get_voxel`` / ``get_voxel_zspectrum`` so that ``unprojection_us()`` reads the kernel's time INSIDE the replayed step (between
         the camera fetch before it and the convolutions behind it), not that of a stand-alone launch."""
@@ -76,10 +76,22 @@ class GraphedRootNet:
                 # instance attributes: shadow the methods while capturing only (get_voxel_zspectrum: the unprojection fused
                 # with the opening conv's z pass, what the root net calls on the root grid since round 6)
                 pl.get_voxel, pl.get_voxel_zspectrum = timed(pl.get_voxel), timed(pl.get_voxel_zspectrum)
+            # ``copies`` > 1: the same step captured into several graph executables that are replayed in turn.  One executable
+            # cannot overlap with itself - the runtime starts replay i + 1 of an executable only after replay i has
+            # completed, which leaves the GPU idle for a launch latency between steps; with two executables the next
+            # step's packets are queued while the current one runs.  Outputs alternate: ``__call__`` returns the tensors of
+            # the copy it launched, valid until that copy is launched again (``copies`` steps later).
+            self.copies = max(1, int(copies))
+            self._graphs, self._outs = [], []
             try:
-                with torch.cuda.graph(self.graph), torch.no_grad():
-                    _lib.fetch_ring(self._ring, self.cam_dev, self._counter)
-                    self.out = net(self.static_hms, meta, flip_xcoords)
+                for _ in range(self.copies):
+                    gr = self.graph if not self._graphs else torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr), torch.no_grad():
+                        _lib.fetch_ring(self._ring, self.cam_dev, self._counter)
+                        out = net(self.static_hms, meta, flip_xcoords)
+                    self._graphs.append(gr)
+                    self._outs.append(out)
+                self.out = self._outs[0]
             finally:
                 if time_unprojection:
                     del pl.get_voxel, pl.get_voxel_zspectrum
@@ -107,8 +119,10 @@ class GraphedRootNet:
     def __call__(self, meta=None):
         """one step: pack the (possibly new) camera table into the ring, replay"""
         self._stage(self._meta if meta is None else meta)
-        self.graph.replay()
+        k = (self._launches - 1) % self.copies
+        self._graphs[k].replay()
         self._events[(self._launches - 1) % self.RING].record(torch.cuda.current_stream(self._dev))
+        self.out = self._outs[k]
         return self.out
 
 
