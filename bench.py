@@ -362,7 +362,7 @@ def roofline_leg(cfg, meta, hms, model, iters, dev, planar_input, cold=True):
         out["kernel_us_in_step"] = round(t_in * 1e3, 2)
         out["frac_in_step"] = round(alg_bytes / (t_in * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["frac_in_step_source"] = ("HIP events around the kernel alone, launched behind a 512 MiB fill (cold L2 / Infinity "
-                                      f"Cache), median of {n_cc}; rocprofv3 in-graph average: profiles/r04_bench_kernel_stats.md")
+                                      f"Cache), median of {n_cc}; rocprofv3 in-graph average: profiles/r06_bench_kernel_stats.md")
     if cold:
         nset = 8
         sets = [_lib.pack_heatmaps([torch.rand_like(x) for x in planar], jp=16) for _ in range(nset)]
