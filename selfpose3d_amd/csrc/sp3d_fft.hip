@@ -136,7 +136,6 @@ __global__ __launch_bounds__(256) void zdft_fwd_cl_kernel(const float *__restric
 {
     static_assert(C == 16 && (Z * C) % 4 == 0, "16 channels x 16 positions = 256 threads");
     constexpr int K = SZ / 2 + 1, P = zd_pitch<Z, C>();
-    constexpr Twiddles<SZ> tw{};
     __shared__ __attribute__((aligned(16))) float tile[ZD_TY * P];
     const int plane = SX * SY;
     const int ntile = (plane + ZD_TY - 1) / ZD_TY;
@@ -160,15 +159,7 @@ __global__ __launch_bounds__(256) void zdft_fwd_cl_kernel(const float *__restric
         float v[Z];
 #pragma unroll
         for (int z = 0; z < Z; ++z) v[z] = tile[yy * P + z * C + c];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int z = 0; z < Z; ++z) {
-                const int m = (k * z) % SZ;
-                re[k] = fmaf(v[z], tw.c[m], re[k]);
-                im[k] = fmaf(v[z], -tw.s[m], im[k]);
-            }
-        }
+        zdft_real<Z, SZ>(v, re, im);
     }
     if (c < Cout && p < plane) {
         float2 *o = out + (((int64_t)b * Cout + c) * K) * plane + p;

@@ -693,6 +693,15 @@ constexpr int BR = 4;
 #ifndef SP3D_BRICK_MINW
 #define SP3D_BRICK_MINW 4
 #endif
+// the ZD form's own gather depth / occupancy target (its workgroups are 5 waves: 3 fit a CU at 4 waves per SIMD, 4 at 5)
+// U = 2: 88 VGPRs -> 5 waves per SIMD -> FOUR 5-wave workgroups per CU instead of three: 37.5 -> 32.9 us warm, 51.8 -> 48.1
+// behind a cache flush (U = 1 / 6 waves: 33.2 / 51.7).  The one-brick workgroups of the other forms keep U = 4 (26.1 vs 24.4 us).
+#ifndef SP3D_ZD_U
+#define SP3D_ZD_U 2
+#endif
+#ifndef SP3D_ZD_MINW
+#define SP3D_ZD_MINW SP3D_BRICK_MINW
+#endif
 // ZD (round 6, root grid only: Z == ZDZ voxels = the whole z extent in ONE stack, JP == 16, float in / out): the workgroup
 // does not store its cubes at all.  Its 4 x 4 columns x Z x J values stay in LDS and leave as the z-SPECTRUM the opening
 // 7^3 conv wants (the direct ZDZ -> ZDSZ/2+1 point DFT of zdft_fwd_cl_kernel, sp3d_fft.hip: same table, same FMA order,
@@ -703,7 +712,7 @@ constexpr int ZDZ = 20, ZDSZ = 28;
 constexpr int SP3D_VARIANT_ZD = 1 << 24;        // launch_nhwc `variant` bit: brick stacks emit the z-spectrum
 constexpr int SP3D_VARIANT_CHUNKS = 1 << 22;    // launch_nhwc `variant` bit: round-5 chunk map of the bricks instead of blocks / octants
 template <int JP, bool OUTCL, typename TI = float, typename TO = float, bool ZD = false>
-__global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
+__global__ __launch_bounds__(512, ZD ? SP3D_ZD_MINW : SP3D_BRICK_MINW) void unproject_brick_kernel(Views hm, const float *__restrict__ cam,
                                                                 const float *__restrict__ centers,
                                                                 const uint8_t *__restrict__ valid,
                                                                 float *__restrict__ cubes, float *__restrict__ grids,
@@ -778,7 +787,7 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
 #else
         unsigned long long *tl = nullptr;
 #endif
-        pipe_views<JP, TI, SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl, (g.xcd_order & 4) != 0);
+        pipe_views<JP, TI, ZD ? SP3D_ZD_U : SP3D_BRICK_U>(hm, cam, g, bs, x, y, z, inb, ws, lane, acc, mymask, tl, (g.xcd_order & 4) != 0);
 
         // view fusion (project_layer.py:96-99) on the gather mapping
         __builtin_amdgcn_wave_barrier();
@@ -837,7 +846,6 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
         // thread -> (column pos = 4 * lx + ly of the tile, channel c): a wave holds 4 channels x 16 columns, its 16-lane groups
         // store 16 complex values = one 128-byte line per (c, kz)
         constexpr int K = ZDSZ / 2 + 1;
-        constexpr Twiddles<ZDSZ> tw{};
         const int pos = tid & 15, c = tid >> 4;
         if (c >= g.J) return;
         float v[ZDZ];
@@ -848,17 +856,10 @@ __global__ __launch_bounds__(512, SP3D_BRICK_MINW) void unproject_brick_kernel(V
         }
         float2 *o = reinterpret_cast<float2 *>(cubes) + ((((size_t)b * g.J + c) * K) * (size_t)g.bk_nxy + (size_t)t) * 16 + pos;
         const size_t kstride = (size_t)g.bk_nxy * 16;
+        float re[K], im[K];
+        zdft_real<ZDZ, ZDSZ>(v, re, im);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float re = 0.0f, im = 0.0f;
-#pragma unroll
-            for (int z = 0; z < ZDZ; ++z) {
-                const int m = (k * z) % ZDSZ;
-                re = fmaf(v[z], tw.c[m], re);
-                im = fmaf(v[z], -tw.s[m], im);
-            }
-            o[(size_t)k * kstride] = make_float2(re, im);
-        }
+        for (int k = 0; k < K; ++k) o[(size_t)k * kstride] = make_float2(re[k], im[k]);
         return;
     }
     // workgroup store of the (J, 4, 4, 4*zw) block: thread -> (channel phase jj, column, brick of the stack)

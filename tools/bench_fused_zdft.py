@@ -10,6 +10,8 @@ import torch
 from selfpose3d_amd import _lib, synthetic as syn
 from selfpose3d_amd.camera_pack import pack_cameras
 
+if os.environ.get("SP3D_LIB"):                      # a measurement build instead of the shipped library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SP3D_LIB"])
 dev = torch.device("cuda:0")
 B, V, J, img, hm, cube = 4, 5, 15, (960, 512), (240, 128), (80, 80, 20)
 S = (88, 88, 28)
