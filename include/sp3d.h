@@ -328,6 +328,15 @@ int sp3d_unproject_fwd_zdft(const float *const *hm_views, int Jp, const float *c
                             const float grid_size[3], int W_in, int H_in, int SZ, void *stream);
 int sp3d_cfft2d_88_tiled(const float *tiled, float *planes, int batch, int X, int Y, void *stream);
 
+/* Round 6: the forward channel contraction of the frequency-domain opening conv (v2v_net.py:113-117, 7x7x7 taps) with the
+ * weight spectrum's transform along y done per bin instead of stored: Y[b,o,row,ky] = sum_c X[b,c,row,ky] * W^[o,c,row,ky],
+ * W^ = G_3 + sum_{u=1..3} S_u cos(2 pi ky u / SY) + i D_u sin(2 pi ky u / SY).  T (rows, O, C, 14) fp32 holds
+ * (G_3, S_1, D_1, S_2, D_2, S_3, D_3) as complex pairs - the taps transformed along the other two axes (rows = their bins),
+ * sums and differences of the +-u taps; tw (SY, 3, 2) = (cos, sin).  12.6x fewer weight bytes than sp3d_freq_contract's
+ * full spectrum (17.7 MB instead of 223 MB on the root grid).  C <= 16, 4 * SY <= 384. */
+int sp3d_freq_contract_ty(const float *X, const float *T, const float *tw, float *Y, int B, int C, int O, int rows, int SY,
+                          void *stream);
+
 /*
  * Synthetic-root branch of the self-supervised root net (lib/models/cuboid_proposal_net_soft.py:151-241):
  *   sp3d_gaussian_target_3d   :168-203  target (B,X,Y,Z) = clip(max over the R roots of a 3-sigma-windowed 3D

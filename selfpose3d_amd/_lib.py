@@ -30,7 +30,7 @@ ABI_VERSION = 3
 EXPORTS = [
     "sp3d_abi_version", "sp3d_error_string", "sp3d_pack_heatmaps", "sp3d_unproject_fwd", "sp3d_unproject_bwd",
     "sp3d_nms_topk_workspace_bytes", "sp3d_nms_topk", "sp3d_nms_proposals", "sp3d_soft_argmax", "sp3d_unproject_fwd_indexed",
-    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_unproject_fwd_zdft", "sp3d_cfft2d_88_tiled", "sp3d_soft_argmax_grid", "sp3d_soft_argmax_grid_train", "sp3d_soft_argmax_grid_bwd", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
+    "sp3d_unproject_bwd_indexed", "sp3d_unproject_fwd_strided", "sp3d_fetch_ring", "sp3d_maxpool2x_cl", "sp3d_crop_shift_act_cl", "sp3d_rfft3d", "sp3d_irfft3d", "sp3d_cfft2d", "sp3d_cfft2d_ex", "sp3d_zdft_fwd_cl", "sp3d_zdft_inv_cl", "sp3d_unproject_fwd_zdft", "sp3d_cfft2d_88_tiled", "sp3d_freq_contract_ty", "sp3d_soft_argmax_grid", "sp3d_soft_argmax_grid_train", "sp3d_soft_argmax_grid_bwd", "sp3d_channel_shift_act", "sp3d_pack_heatmaps_ex",
     "sp3d_unproject_fwd_train", "sp3d_unproject_bwd_packed", "sp3d_unproject_bwd_packed_det", "sp3d_fixed_to_float", "sp3d_gaussian_target_3d", "sp3d_render_root_heatmaps", "sp3d_freq_contract", "sp3d_freq_contract_ex", "sp3d_wino_input", "sp3d_wino_output", "sp3d_wino_fused", "sp3d_wino_fused_split", "sp3d_wino_fused_split64", "sp3d_conv3_split", "sp3d_camera_finish", "sp3d_upsample2x_scatter", "sp3d_upsample2x_scatter_head", "sp3d_render_joints_fwd", "sp3d_render_joints_bwd", "sp3d_gbn_workspace_bytes", "sp3d_gbn_forward", "sp3d_gbn_backward",
 ]
 
@@ -675,6 +675,24 @@ def freq_contract(Xf: torch.Tensor, Wf: torch.Tensor) -> torch.Tensor:
     Yf = torch.empty((B, O) + tuple(Xf.shape[2:]), dtype=torch.complex64, device=Xf.device)
     check(lib.sp3d_freq_contract(Xf.data_ptr(), Wf.data_ptr(), Yf.data_ptr(), B, Cc, O, Fn, _stream(Xf.device)),
           "sp3d_freq_contract")
+    return Yf
+
+
+def freq_contract_ty(Xf: torch.Tensor, T: torch.Tensor, tw: torch.Tensor) -> torch.Tensor:
+    """Xf (B,C,KZ,SX,SY) complex64, T (KZ*SX, O, C, 14) fp32 (v2v_net._FoldedV2V._weights_ty), tw (SY,3,2) fp32
+    -> (B,O,KZ,SX,SY) complex64: the forward contraction with W^ rebuilt per bin along y (include/sp3d.h)"""
+    lib = load()
+    _require_cuda(Xf, "Xf")
+    B, Cc, KZ, SX, SY = (int(v) for v in Xf.shape)
+    rows, O = int(T.shape[0]), int(T.shape[1])
+    if Xf.dtype != torch.complex64 or not Xf.is_contiguous() or T.dtype != torch.float32 or not T.is_contiguous() or \
+            tuple(T.shape) != (KZ * SX, O, Cc, 14) or tuple(tw.shape) != (SY, 3, 2) or not tw.is_contiguous():
+        raise Sp3dError("freq_contract_ty: (B,C,KZ,SX,SY) complex64 x (KZ*SX,O,C,14) fp32 table expected")
+    Yf = torch.empty((B, O, KZ, SX, SY), dtype=torch.complex64, device=Xf.device)
+    lib.sp3d_freq_contract_ty.restype = C.c_int
+    lib.sp3d_freq_contract_ty.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+    check(lib.sp3d_freq_contract_ty(Xf.data_ptr(), T.data_ptr(), tw.data_ptr(), Yf.data_ptr(), B, Cc, O, rows, SY,
+                                    _stream(Xf.device)), "sp3d_freq_contract_ty")
     return Yf
 
 

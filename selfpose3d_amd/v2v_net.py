@@ -464,6 +464,45 @@ class _FoldedV2V:
                 del self.t[wkey]                       # nobody asked for the planar buffer: keep one spectrum only
         return self.t[zkey]
 
+    def _weights_ty(self, w0, S):
+        """(T, tw) of _lib.freq_contract_ty: the opening conv's taps transformed along z and x only (float64 on the host
+        side of the plan build, stored fp32), as (G_p, S_1, D_1, ..., S_p, D_p) per (row = (kz, kx), o, c), and the
+        (cos, sin)(2 pi ky u / SY) table.  W^[o,c,kz,kx,ky] = conj(rfftn(taps centred on the origin)) / N is what the kernel
+        rebuilds from them per bin (csrc/sp3d_fftconv.hip)."""
+        key = ("Wty", S)
+        if key not in self.t:
+            import math
+            k = int(w0.shape[2])
+            p = k // 2
+            SX, SY, SZ = S
+            w = w0.detach().double().cpu()                                       # (O, C, tx, ty, tz)
+            t = torch.arange(k, dtype=torch.float64) - p
+            ex = torch.exp(2j * math.pi * torch.arange(SX, dtype=torch.float64)[:, None] * t[None, :] / SX)            # (kx, tx)
+            ez = torch.exp(2j * math.pi * torch.arange(SZ // 2 + 1, dtype=torch.float64)[:, None] * t[None, :] / SZ)   # (kz, tz)
+            G = torch.einsum("ocxyz,kx,mz->mkocy", w.to(torch.complex128), ex, ez) / float(SX * SY * SZ)            # (kz,kx,O,C,ty)
+            cols = [G[..., p]]
+            for u in range(1, p + 1):
+                cols += [G[..., p + u] + G[..., p - u], G[..., p + u] - G[..., p - u]]
+            T = torch.view_as_real(torch.stack(cols, -1))                        # (kz,kx,O,C,1+2p,2)
+            T = T.reshape(G.shape[0] * G.shape[1], G.shape[2], G.shape[3], 2 * (1 + 2 * p)).float().contiguous()
+            ang = 2.0 * math.pi * torch.arange(SY, dtype=torch.float64)[:, None] * torch.arange(1, p + 1, dtype=torch.float64)[None, :] / SY
+            tw = torch.stack([torch.cos(ang), torch.sin(ang)], -1).float().contiguous()
+            self.t[key] = (T.to(w0.device), tw.to(w0.device))
+        return self.t[key]
+
+    def _contract(self, Xs, w0, S):
+        """channel contraction of the opening conv on the kz-slowest spectrum: with the weight spectrum's y transform rebuilt
+        per bin (17.7 MB of table instead of 223 MB of spectrum on the root grid) when the kernel covers the shape"""
+        from . import _lib
+        import os
+        # measured (profiles/r06_contract_ty.md): 12.6x fewer weight bytes, but no faster in the step (1.4512 vs 1.4507 ms) - the
+        # rebuilt spectrum costs the VALU what the stream cost the HBM.  Opt-in: V2VNet.contract_ty = True / SP3D_CONTRACT_TY=1.
+        on = getattr(self.net, "contract_ty", os.environ.get("SP3D_CONTRACT_TY", "0") not in ("0", ""))
+        if on and int(w0.shape[2]) == 7 and int(w0.shape[1]) <= 16 and 4 * S[1] <= 384:
+            T, tw = self._weights_ty(w0, S)
+            return _lib.freq_contract_ty(Xs, T, tw)
+        return _lib.freq_contract(Xs, self._weights_z(w0, S))
+
     def _front_zspectrum(self, z: "TiledZSpectrum", w0, s0):
         """opening conv when the unprojection already delivered the z-spectrum (round 6): x,y plane transforms (un-tiling
         on load) -> contraction -> inverse x,y -> inverse z-DFT + shift + ReLU.  Same kernels and bits as the cubes path of
@@ -474,7 +513,7 @@ class _FoldedV2V:
         if S[2] != z.SZ or S[0] != 88 or S[1] != 88 or int(w0.shape[1]) != z.shape[1] or int(w0.shape[0]) != 16:
             raise _lib.Sp3dError(f"TiledZSpectrum of {z.shape} (SZ {z.SZ}) does not fit this net's opening conv (FFT shape {S})")
         Xs = _lib.cfft2d_88_tiled(z.spec, z.X, z.Y)
-        Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self._weights_z(w0, S)), True, rows_out=z.X)
+        Ys = _lib.cfft2d_(self._contract(Xs, w0, S), True, rows_out=z.X)
         return _lib.zdft_inv_cl(Ys, z.X, z.Y, z.Z, S[2], s0, True)
 
     def _front_fft(self, x, w0, s0):
@@ -504,7 +543,7 @@ class _FoldedV2V:
                 if not any(k[0] == "xpad" for k in self.t if isinstance(k, tuple)):
                     del self.t[wkey]                       # nobody asked for the planar buffer: keep one spectrum only
             Xs = _lib.cfft2d_(_lib.zdft_fwd_cl(x, cin, S), False, rows_in=X)          # rows x >= X are zero padding
-            Ys = _lib.cfft2d_(_lib.freq_contract(Xs, self.t[zkey]), True, rows_out=X)   # ... and not read on the way back
+            Ys = _lib.cfft2d_(self._contract(Xs, w0, S), True, rows_out=X)              # ... and not read on the way back
             return _lib.zdft_inv_cl(Ys, X, Y, Z, S[2], s0, True)
         if self._is_padded_view(x, cin, S):
             # x IS the signal corner of this plan's zero-padded buffer (fft_input_view / input_chunk_views): no pad/copy

@@ -132,3 +132,29 @@ def test_root_net_fused_equals_unfused(dev, graph):
     assert called[True] > 0 and called[False] == 0                  # the switch really selects the path
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
     _check_root(outs[True][0], outs[True][1], g)
+
+
+def test_contraction_with_the_y_transform_rebuilt_per_bin(dev):
+    """sp3d_freq_contract_ty (17.7 MB table of the taps transformed along z and x) against sp3d_freq_contract on the full
+    223 MB weight spectrum (conj(rfftn(taps)) / N, what the plan used until round 6) and against a float64 evaluation"""
+    from selfpose3d_amd import _lib
+    from selfpose3d_amd.v2v_net import V2VNet, _FoldedV2V
+    torch.manual_seed(5)
+    net = V2VNet(15, 1).to(dev).eval()
+    plan = _FoldedV2V(net)
+    plan._build()
+    plan.key = plan._key(net)
+    w0, s0 = plan.t["front"]
+    S = (88, 88, 28)
+    Wz = plan._weights_z(w0, S)                                           # (16,15,15,88,88)
+    T, tw = plan._weights_ty(w0, S)
+    assert T.shape == (15 * 88, 16, 15, 14) and tw.shape == (88, 3, 2)
+    for B in (4, 1, 6):
+        X = torch.view_as_complex(torch.randn((B, 15, 15, 88, 88, 2), device=dev))
+        ref = _lib.freq_contract(X, Wz)
+        got = _lib.freq_contract_ty(X, T, tw)
+        exact = torch.einsum("bckxy,ockxy->bokxy", X.to(torch.complex128), Wz.to(torch.complex128))
+        scale = float(exact.abs().max())
+        e_ref, e_got = float((ref - exact).abs().max()) / scale, float((got - exact).abs().max()) / scale
+        assert e_got <= max(2.0 * e_ref, 2e-6), (B, e_got, e_ref)
+        assert float((got - ref).abs().max()) / scale <= 4e-6

@@ -75,6 +75,17 @@ for cold in (False, True):
         "chain_two_kernels": t(lambda: _lib.cfft2d_(_lib.zdft_fwd_cl(unproj(), J, S), False, rows_in=80), cold=cold),
         "chain_fused": t(lambda: _lib.cfft2d_88_tiled(fused(), 80, 80), cold=cold),
     }
+# round 6, second step: the channel contraction with the weight spectrum's y transform rebuilt per bin
+from selfpose3d_amd.v2v_net import V2VNet, _FoldedV2V
+net = V2VNet(15, 1).to(dev).eval()
+plan = _FoldedV2V(net); plan._build(); plan.key = plan._key(net)
+w0, _s0 = plan.t["front"]
+Wz = plan._weights_z(w0, S); Tt, tw = plan._weights_ty(w0, S)
+Xs = _lib.cfft2d_88_tiled(spec1, 80, 80)
+for cold in (False, True):
+    k = "cold" if cold else "warm"
+    out[k]["freq_contract_full_spectrum"] = t(lambda: _lib.freq_contract(Xs, Wz), cold=cold)
+    out[k]["freq_contract_ty"] = t(lambda: _lib.freq_contract_ty(Xs, Tt, tw), cold=cold)
 alg = 4 * B * (V * J * hm[0] * hm[1] + J * 80 * 80 * 20)
 out["algorithmic_bytes_unprojection"] = alg
 out["bytes_fused_kernel_actually_moves"] = 4 * B * V * 16 * hm[0] * hm[1] + 8 * B * J * 15 * 80 * 80
