@@ -225,6 +225,59 @@ def g_render_ssv_full():
           f"{time.time() - t0:.1f} s; {os.path.getsize(os.path.join(HERE, 'render_ssv_full.npz')) / 1e6:.2f} MB")
 
 
+def g_train_step_full():
+    """reference MultiPersonPoseNet.forward in TRAIN mode at BASELINE configs[2]'s sizes, proposals from ground truth
+    (lib/models/multi_person_posenet.py:36-102 with USE_GT): losses, the gradient of backbone.final_layer.weight and of the
+    pose net's output layer, in fp32 and in a float64 rerun (the yardstick, as g_train_step of make_goldens_r3.py)."""
+    import models.multi_person_posenet as mp
+    import utils.cameras as ref_cameras
+    import models.project_layer as ref_pl
+    t0 = time.time()
+    t = gio.TRAIN_FULL
+    cfg = mg2.full_cfg(t["img"], t["hm"], t["cube"], t["fine_cube"], t["J"], num_layers=t["layers"], batch=2, SIGMA=t["sigma"],
+                       USE_GT=True)
+    cfg.MULTI_PERSON.MAX_PEOPLE_NUM = t["max_people"]
+    cfg.MULTI_PERSON.THRESHOLD = t["threshold"]
+    rec = {"param_seed": 183, "data_seed": 6}
+
+    def run(double):
+        model = mp.get_multi_person_pose_net(cfg, is_train=True)
+        gio.he_fill(model, seed=rec["param_seed"])
+        inputs, t2d, w2d, t3d, meta, _ = gio.train_batch(gio.train_full_cfg(USE_GT=True), B=2, seed=rec["data_seed"])
+        if double:
+            model.double()
+            dd = lambda x: [v.double() for v in x]
+            inputs, t2d, w2d, t3d = dd(inputs), dd(t2d), dd(w2d), dd(t3d)
+        model.train()
+        pred, hms, gc, l2d, l3d, lcord = model(views=inputs, meta=meta, targets_2d=t2d, weights_2d=w2d, targets_3d=t3d[0])
+        (l2d.mean() + l3d.mean() + lcord.mean()).backward()
+        return model, pred, hms, gc, l2d, l3d, lcord
+
+    model, pred, hms, gc, l2d, l3d, lcord = run(False)
+    print(f"  fp32 pass {time.time() - t0:.0f} s: losses", float(l2d), float(l3d), float(lcord), "valid", int((gc[:, :, 3] >= 0).sum()))
+    rec.update(loss_2d=float(l2d), loss_3d=float(l3d), loss_cord=float(lcord), grid_centers=gc.detach().numpy(),
+               pred=pred.detach().numpy(), hm_sum=np.array([float(h.double().sum()) for h in hms]),
+               grad_final=model.backbone.final_layer.weight.grad.numpy().copy(),
+               grad_pose_out=model.pose_net.v2v_net.output_layer.weight.grad.numpy().copy(),
+               grad_conv1_sub=model.backbone.conv1.weight.grad.numpy().reshape(-1)[::7].copy())
+    del model
+    unfold32, xform32 = ref_cameras.unfold_camera_param, ref_pl.do_transform
+    try:
+        ref_pl.do_transform = lambda pts, tt: xform32(pts, tt.to(pts.dtype))
+        ref_cameras.unfold_camera_param = lambda cam, device=None: tuple(v.double() for v in unfold32(cam, device))
+        torch.set_default_dtype(torch.float64)
+        m64, _, _, _, a2, a3, ac = run(True)
+        rec.update(loss_2d_f64=float(a2), loss_3d_f64=float(a3), loss_cord_f64=float(ac),
+                   grad_final_f64=m64.backbone.final_layer.weight.grad.numpy().copy(),
+                   grad_pose_out_f64=m64.pose_net.v2v_net.output_layer.weight.grad.numpy().copy(),
+                   grad_conv1_sub_f64=m64.backbone.conv1.weight.grad.numpy().reshape(-1)[::7].copy())
+    finally:
+        torch.set_default_dtype(torch.float32)
+        ref_cameras.unfold_camera_param, ref_pl.do_transform = unfold32, xform32
+    np.savez_compressed(os.path.join(HERE, "train_step_full.npz"), **rec)
+    print(f"train_step_full: {time.time() - t0:.0f} s, {os.path.getsize(os.path.join(HERE, 'train_step_full.npz')) / 1e6:.2f} MB")
+
+
 def g_config_schema():
     easydict = type(sys)("easydict")
     easydict.EasyDict = mg.AD
@@ -236,7 +289,7 @@ def g_config_schema():
     print("config_schema:", len(out), "top-level names,", sum(len(v) for v in out.values() if v), "section keys")
 
 
-ALL = {"config_schema": g_config_schema, "unproj_coarse_b4": g_unproj_coarse_b4,
+ALL = {"train_step_full": g_train_step_full, "config_schema": g_config_schema, "unproj_coarse_b4": g_unproj_coarse_b4,
        "unproj_grad_root_full": g_unproj_grad_root_full, "unproj_grad_fine_full": g_unproj_grad_fine_full,
        "render_ssv_full": g_render_ssv_full}
 
@@ -244,5 +297,5 @@ if __name__ == "__main__":
     mg2.install_shims()
     torch.nn.Module.cuda = lambda self, device=None: self        # no GPU here; the reference calls .cuda() on loss modules
     torch.set_num_threads(8)
-    for nm in (sys.argv[1:] or list(ALL)):
+    for nm in (sys.argv[1:] or [k for k in ALL if k != "train_step_full"]):      # (train_step_full: ~30 min of CPU, run by name)
         ALL[nm]()

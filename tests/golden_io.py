@@ -139,6 +139,22 @@ def render_cfg():
         TRAIN_SMALL = keep
 
 
+# ---- round 6: one supervised train step at FULL size (tests/golden/make_goldens_r6.py g_train_step_full) --------------------
+TRAIN_FULL = dict(img=(960, 512), hm=(240, 128), V=5, J=15, cube=(80, 80, 20), fine_cube=(64, 64, 64), max_people=10,
+                  layers=50, threshold=0.3, sigma=3)
+
+
+def train_full_cfg(**net):
+    """BASELINE configs[2]'s sizes (ResNet-50, 5 x 960x512, 80x80x20 root grid, 64^3 pose cubes, batch 2)"""
+    global TRAIN_SMALL
+    keep = TRAIN_SMALL
+    TRAIN_SMALL = TRAIN_FULL
+    try:
+        return train_cfg(**net)
+    finally:
+        TRAIN_SMALL = keep
+
+
 # ---- round 4: the pose stage at full size (tests/golden/make_goldens_r4.py) --------------------------------------------
 POSENET_FULL = dict(img=(960, 512), hm=(240, 128), V=5, J=15, B=2, fine_cube=(64, 64, 64), hm_seed=411, pose_seed=413,
                     param_scale=0.05, stride=211)
