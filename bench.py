@@ -47,7 +47,8 @@ import torch
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-EXIT_LEGS_INCOMPLETE = 3      # world > 1: the line was printed, but a leg hung / failed or RCCL did not span every rank
+EXIT_LEGS_INCOMPLETE = 3      # world > 1: the line was printed, but a leg hung, a leg with a collective failed or RCCL did not span every rank
+COLLECTIVE_LEGS = ("data_plane", "train_step", "train_step_ssv")
 
 
 def parse():
@@ -1031,11 +1032,15 @@ def main():
             result.setdefault("legs", extra)
             # top level, where a driver looks: did every leg return, and may this line be one point of a scaling curve?
             # (false: the deadline fired, the final barrier failed, a leg recorded an error, or the data-plane communicator
-            # did not span every rank - in each case the process also exits with EXIT_LEGS_INCOMPLETE)
+            # did not span every rank; the process exits with EXIT_LEGS_INCOMPLETE when scaling_valid is false)
             failed = [k for k, v in list(extra.items()) if isinstance(v, dict) and "error" in v]
             result["legs_complete"] = line_state["incomplete"] is None and not failed
             seen = line_state["rccl_ranks_seen"]
-            result["scaling_valid"] = bool(result["legs_complete"] and (world == 1 or seen == world))
+            # scaling_valid: nothing hung, the communicator spanned every rank and the legs that USE it returned; an error record
+            # of a leg without a collective (rank 0's kernel legs) makes the run incomplete, not the scaling point invalid
+            collective_failed = [k for k in failed if k in COLLECTIVE_LEGS]
+            result["scaling_valid"] = bool(line_state["incomplete"] is None and not collective_failed and
+                                           (world == 1 or seen == world))
             if failed:
                 result["legs_failed"] = failed
             for attempt in range(5):                 # the deadline thread may serialise while the main thread adds a leg
@@ -1212,8 +1217,8 @@ def main():
     if world > 1:
         # every rank agrees on the status without another collective: the deadline / barrier note is local knowledge, a leg's
         # error record is the same exception on every rank (all ranks run the legs alike)
-        bad = line_state["incomplete"] is not None or any(isinstance(v, dict) and "error" in v for v in extra.values()) or \
-            line_state["rccl_ranks_seen"] != world
+        bad = line_state["incomplete"] is not None or line_state["rccl_ranks_seen"] != world or \
+            any(isinstance(extra.get(k), dict) and "error" in extra[k] for k in COLLECTIVE_LEGS)
         if bad:
             raise SystemExit(EXIT_LEGS_INCOMPLETE)
 
