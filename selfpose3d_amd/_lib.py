@@ -15,7 +15,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT_LIB_PATH = os.path.join(_HERE, "libsp3d.so")
 NOPK_LIB_PATH = os.path.join(_HERE, "libsp3d_nopk.so")       # the flavour without packed-fp32 instructions (shared GPUs)
-LIB_PATH = _DEFAULT_LIB_PATH
+# SP3D_LIB_PATH: a measurement / sanitizer build of the SAME sources instead of the shipped library (tools/sanitize_host.py)
+LIB_PATH = os.environ.get("SP3D_LIB_PATH") or _DEFAULT_LIB_PATH
 
 LAYOUT_PLANAR = 0
 LAYOUT_NHWC = 1
