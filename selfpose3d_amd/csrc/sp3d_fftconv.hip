@@ -104,7 +104,13 @@ __global__ __launch_bounds__(FT_NT, SP3D_FT_MINW) void freq_contract_ty_kernel(c
                                                                  int C, int O, int rows, int SY)
 {
     __shared__ __attribute__((aligned(16))) float tab[FT_ROWS * OG * FT_CMAX * FT_W];
-    const int row0 = blockIdx.x * FT_ROWS, o0 = blockIdx.y * OG, b0 = blockIdx.z * BB;
+    // workgroup i runs on XCD i % 8: the O / OG output groups of one block of rows get ids 8 apart, i.e. the SAME XCD one after
+    // the other, so that X is fetched into that L2 once (2-D grid: every group landed on another XCD and X crossed the fabric
+    // O / OG times - 236 MB per launch for 56 MB of X, PMC)
+    const int nog = (O + OG - 1) / OG;
+    const int gid = blockIdx.x, rb = (gid / (8 * nog)) * 8 + (gid & 7), ogi = (gid >> 3) % nog;
+    const int row0 = rb * FT_ROWS, o0 = ogi * OG, b0 = blockIdx.z * BB;
+    if (row0 >= rows) return;
     const int t = threadIdx.x;
     const int og = min(OG, O - o0);
     // stage: per row a contiguous run of og * C * FT_W floats of T
@@ -171,7 +177,8 @@ extern "C" int sp3d_freq_contract_ty(const float *X, const float *T, const float
     if (B <= 0 || C <= 0 || O <= 0 || rows <= 0 || SY <= 0) return SP3D_EINVAL;
     if (!X || !T || !tw || !Y) return SP3D_ENULL;
     if (C > FT_CMAX || FT_ROWS * SY > FT_NT) return SP3D_EUNSUPPORTED;
-    const dim3 grid((unsigned)((rows + FT_ROWS - 1) / FT_ROWS), (unsigned)((O + SP3D_FT_OG - 1) / SP3D_FT_OG), (unsigned)((B + 3) / 4));
+    const int nrb = (rows + FT_ROWS - 1) / FT_ROWS, nog = (O + SP3D_FT_OG - 1) / SP3D_FT_OG;
+    const dim3 grid((unsigned)(((nrb + 7) / 8) * 8 * nog), 1, (unsigned)((B + 3) / 4));
     hipLaunchKernelGGL((freq_contract_ty_kernel<4, SP3D_FT_OG>), grid, dim3(FT_NT), 0, (hipStream_t)stream, reinterpret_cast<const float2 *>(X), T,
                        tw, reinterpret_cast<float2 *>(Y), B, C, O, rows, SY);
     const hipError_t e = hipGetLastError();
