@@ -247,7 +247,7 @@ class HostShare:
     GPUs, /root/reference/tools/train_3d.py:105-140; here it is one process per GPU).
     (Round 5, first form: a spinner on EVERY other logical CPU, 224 of them - the step took 11x longer although none shared
     a core with this process: the box's container has a CPU quota, which the spinners exhaust for everybody.  Recorded in
-    DESIGN.md; eight real ranks need ~16 cores, not 256.)"""
+    docs/history_r1-r5.md; eight real ranks need ~16 cores, not 256.)"""
 
     def __init__(self, burners: bool = False, shares: int = 8, busy_per_rank: int = 2, max_seconds: int = 600):
         self.burners, self.shares, self.busy_per_rank, self.max_seconds = burners, shares, busy_per_rank, int(max_seconds)
